@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the per-pixel ray-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame: every pixel's primary ray, nearest hit over all surfaces, shadow rays to all lights,
+Lambert shading and the mirror-bounce loop, written to an RGBA32F framebuffer resident in HBM.
+Metric (BASELINE.json): Mrays/s on scenes/20spheres.yml; a ray = one primary, shadow or reflection ray
+(SURVEY.md 8(d)); rays per frame are counted by the kernel itself (RT_FLAG_COUNT pass before timing).
+
+N = 1: BASELINE config 2, 20spheres @ 1920x1080, camera = identity (the reference host's start-up pose).
+N > 1: weak scaling -- the same scene at N x the pixels (same 16:9 aspect), rows band-cyclic over the ranks
+(no data-path communication while rendering), one RCCL gather of the tiles to rank 0 per frame + a device
+reassembly kernel on rank 0, as BASELINE.json's north_star prescribes.
+
+Prints ONE JSON line (rank 0).  The oracle (oracle/) is used ONLY for the `cpu_baseline` leg.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz = half the FP32 vector
+                                 # peak (157.3 TF, MI355X_MICROARCH.md chip table); checked by profiles/*fp64_peak*
+HBM_PEAK_GBS = 8000.0
+
+
+def workload_for(n_gpus, name):
+    if name == "config5":
+        return "20spheres", 7680, 4320, None
+    if name == "config3":
+        return "reflection_test", 1920, 1080, 4
+    if name == "config4":
+        return "clebsch", 3840, 2160, None
+    s = math.sqrt(n_gpus)
+    w = int(round(1920 * s / 16.0)) * 16
+    h = int(round(w * 9 / 16.0))
+    return "20spheres", w, h, None
+
+
+def algorithmic_flops(cnt, classes):
+    """FP64 operations of the KERNEL'S OWN algorithm for one frame (DESIGN.md "Flop accounting"):
+    per-unit figures x the units the kernel counted.  add/sub/mul/div/sqrt = 1 each (an FMA would be 2);
+    never more than the reference's dense 286 + solver per test."""
+    # per ray: 27 mul + 9 add monomials; per primary ray +~45 (direction); per hit +~120 (point, normal, bias)
+    per_test = {"unitsq": 17.0, "square": 38.0, "cross": 59.0, "linear": 14.0, "cubic": 286.0 + 30.0}
+    mix = sum(per_test[c] for c in classes) / max(1, len(classes))
+    rays = cnt["primary_rays"] + cnt["shadow_rays"] + cnt["reflect_rays"]
+    return cnt["tests"] * mix + rays * 36.0 + cnt["primary_rays"] * 45.0 + cnt["hits"] * 120.0 + cnt["solves"] * 7.0
+
+
+def object_classes(arr):
+    out = []
+    for c in arr["coefs"]:
+        if np.any(c[:10] != 0):
+            out.append("cubic")
+        elif np.any(c[13:16] != 0):
+            out.append("cross")
+        elif np.all(c[10:13] == 1.0):
+            out.append("unitsq")
+        elif np.any(c[10:13] != 0):
+            out.append("square")
+        else:
+            out.append("linear")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="config2", help="config2 (default, weak-scaled with --gpus) | config3 | config4 | config5")
+    ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
+    ap.add_argument("--band-rows", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ray-tracing path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = graft.load_package()
+    scene_name, W, H, max_refl = workload_for(world, args.workload)
+    scene = pkg.Scene.load_from_file(os.path.join(ROOT, "scenes", scene_name + ".yml")).set_size(W, H)
+    if max_refl is not None:
+        scene.set_max_reflections(max_refl)
+    flags = pkg.RT_FLAG_FAST if args.mode == "fast" else pkg.RT_FLAG_STRICT
+    band = args.band_rows
+    cam = pkg.IDENTITY
+
+    # ---- ray accounting: one counting frame (not timed) ----
+    rc = pkg.Renderer(scene, device=local_rank, rank=rank, world=world, band_rows=band, flags=flags | pkg.RT_FLAG_COUNT)
+    rc.update(cam)
+    cnt = rc.counters()
+    rc.cleanup_update()
+    keys = ["primary_rays", "shadow_rays", "reflect_rays", "tests", "hits", "solves"]
+    tot = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot)
+    total = {k: int(v) for k, v in zip(keys, tot.tolist())}
+    rays_per_frame = total["primary_rays"] + total["shadow_rays"] + total["reflect_rays"]
+
+    # ---- the timed path ----
+    ren = pkg.Renderer(scene, device=local_rank, rank=rank, world=world, band_rows=band, flags=flags)
+    mx = ren.max_local_rows
+    stream = torch.cuda.current_stream(dev)
+    local = torch.empty((mx, W, 4), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world, mx, W, 4), dtype=torch.float32, device=dev) if (rank == 0 and world > 1) else None
+    full = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if (rank == 0 and world > 1) else None
+
+    def step():
+        ren.update(cam, dev_fb=local.data_ptr(), stream=stream.cuda_stream, timed=False)
+        if world > 1:
+            g = pkg.gather_to_root(local, world, rank, gathered=gathered)
+            if rank == 0:
+                ren.assemble(g.data_ptr(), full.data_ptr(), stream=stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ev_ms = ev0.elapsed_time(ev1)
+
+    # per-launch duration of the dominant kernel from HIP events on its own stream (N=1: the timed region is K
+    # back-to-back launches of it; N>1: measured in a short extra pass, the timed region also holds the gather)
+    if world == 1:
+        kernel_ms = ev_ms / args.steps
+    else:
+        kernel_ms = float(np.mean([ren.update(cam, dev_fb=local.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(10)]))
+
+    result = None
+    if rank == 0:
+        arr = scene.arrays()
+        local_cnt = {k: cnt[k] for k in keys}
+        flops_launch = algorithmic_flops(local_cnt, object_classes(arr))
+        achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
+        dense_equiv = (total["tests"] * 290.0) / (dt / args.steps) / 1e12  # reference's as-written count, for comparison
+        fb_bytes = float(ren.local_rows) * W * 16.0
+        result = {
+            "metric": "Mrays/sec, 20spheres.yml @1920x1080 (weak-scaled with --gpus)" if args.workload == "config2" else f"Mrays/sec, {args.workload}",
+            "value": rays_per_frame * args.steps / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "frames_per_s": args.steps / dt,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{scene_name}.yml {W}x{H}, camera identity, RGBA32F framebuffer", "objects": int(arr["coefs"].shape[0]),
+                       "lights": int(arr["light_p"].shape[0]), "rays_per_frame": rays_per_frame, "tests_per_frame": total["tests"],
+                       "kernel_mode": args.mode, "parallelism": f"rows band-cyclic x{world} (band {band}), gather to rank 0" if world > 1 else "single GPU"},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "trace_tile_kernel", "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_launch,
+                         "reference_equivalent_tflops": dense_equiv,
+                         "hbm_write_gbs": fb_bytes / (kernel_ms * 1e-3) / 1e9, "hbm_frac": fb_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            O = graft.load_oracle()
+            osc = O.load_scene(os.path.join(ROOT, "scenes", scene_name + ".yml")).with_size(W, H, max_refl)
+            t = time.perf_counter()
+            for _ in range(args.cpu_frames):
+                _, ocnt = osc.render(cam, counters=False, nthreads=1), None
+            cdt = time.perf_counter() - t
+            result["cpu_baseline"] = {"value": rays_per_frame * args.cpu_frames / cdt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+                                      "frames_per_s": args.cpu_frames / cdt,
+                                      "sample": f"{args.cpu_frames} full frames of the same workload ({W}x{H}), 1 thread (the reference's CPU path is serial), "
+                                                f"oracle built gcc -O2 -ffp-contract=off; {cdt:.1f} s"}
+            result["speedup_vs_cpu_1thread"] = result["value"] / result["cpu_baseline"]["value"]
+        print(json.dumps(result), flush=True)
+    ren.cleanup_update()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,480 @@
+// rt_capi.cpp -- C ABI of libmi355rt.so (include/mi355rt.h): scene handles, render contexts, launches.
+//
+// Host side of the HIP path.  No CPU fallback: every render entry point fails with RT_ERR_NO_DEVICE /
+// RT_ERR_DEVICE when there is no usable GPU.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mi355rt.h"
+#include "rt_scene_dev.h"
+#include "scene-exception.h"
+#include "scene.h"
+
+// kernels, one set per floating-point contraction mode (rt_kernels.hip)
+extern "C" hipError_t rt_launch_trace_strict(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, int, hipStream_t);
+extern "C" hipError_t rt_launch_trace_fast(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, int, hipStream_t);
+extern "C" hipError_t rt_launch_assemble_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define RT_HIP(call)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_));      \
+    } while (0)
+
+} // namespace
+
+// Flat arrays the descriptor points into, kept next to the C++ scene model.
+struct rt_scene {
+    Scene scene;
+    std::vector<double> coefs, light_p;
+    std::vector<float> reflection, albedo, light_color;
+    std::vector<uint8_t> light_kind;
+
+    void flatten()
+    {
+        const size_t no = scene.objects.size(), nl = scene.lights.size();
+        coefs.resize(no * RT_NCOEF);
+        reflection.resize(no);
+        albedo.resize(no * 3);
+        for (size_t i = 0; i < no; i++) {
+            const Object &o = scene.objects[i];
+            std::memcpy(&coefs[i * RT_NCOEF], o.surface.data(), sizeof(double) * RT_NCOEF);
+            reflection[i] = o.reflection_ratio;
+            albedo[3 * i + 0] = o.color.x;
+            albedo[3 * i + 1] = o.color.y;
+            albedo[3 * i + 2] = o.color.z;
+        }
+        light_p.resize(nl * 3);
+        light_color.resize(nl * 3);
+        light_kind.resize(nl);
+        for (size_t i = 0; i < nl; i++) {
+            const LightSource &l = scene.lights[i];
+            light_kind[i] = l.is_spherical ? 1 : 0;
+            for (int k = 0; k < 3; k++) {
+                light_p[3 * i + k] = l.p[k];
+                light_color[3 * i + k] = l.light_color[k];
+            }
+        }
+    }
+};
+
+struct rt_ctx {
+    int device = 0;
+    rt_config cfg{};
+    FrameArgs fa{};
+    uint32_t local_rows = 0, max_local_rows = 0;
+    size_t pixel_bytes = 16;
+    DevObject *d_obj = nullptr;
+    DevLight *d_light = nullptr;
+    void *d_fb = nullptr;
+    unsigned long long *d_counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool counted = false;
+};
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+extern "C" const char *rt_last_error(void) { return g_last_error.c_str(); }
+
+// ---- scene --------------------------------------------------------------------------------------------
+extern "C" int rt_scene_load_file(const char *path, rt_scene **out)
+{
+    if (!path || !out) return fail(RT_ERR_INVALID, "rt_scene_load_file: null argument");
+    *out = nullptr;
+    try {
+        rt_scene *s = new rt_scene();
+        try {
+            s->scene = Scene::load_from_file(path);
+        } catch (...) {
+            delete s;
+            throw;
+        }
+        s->flatten();
+        *out = s;
+        return RT_OK;
+    } catch (const SceneException &e) {
+        return fail(RT_ERR_SCENE, "%s", e.what());
+    } catch (const std::bad_alloc &) {
+        return fail(RT_ERR_NOMEM, "out of memory");
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_SCENE, "%s", e.what());
+    }
+}
+
+extern "C" int rt_scene_new(uint32_t width, uint32_t height, double fov_deg, uint32_t max_reflections,
+                            const float bg_color[3], rt_scene **out)
+{
+    if (!out || !bg_color) return fail(RT_ERR_INVALID, "rt_scene_new: null argument");
+    *out = nullptr;
+    try {
+        rt_scene *s = new rt_scene();
+        try {
+            s->scene = Scene(width, height, fov_deg, max_reflections, glm::vec3(bg_color[0], bg_color[1], bg_color[2]));
+        } catch (...) {
+            delete s;
+            throw;
+        }
+        s->flatten();
+        *out = s;
+        return RT_OK;
+    } catch (const SceneException &e) {
+        return fail(RT_ERR_SCENE, "%s", e.what());
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_NOMEM, "%s", e.what());
+    }
+}
+
+extern "C" int rt_scene_add_object(rt_scene *s, const double coefs[RT_NCOEF], float reflection_ratio, const float color[3])
+{
+    if (!s || !coefs || !color) return fail(RT_ERR_INVALID, "rt_scene_add_object: null argument");
+    try {
+        SurfaceCoefs sc{};
+        std::memcpy(sc.data(), coefs, sizeof(double) * RT_NCOEF);
+        s->scene.objects.push_back(Object(sc, reflection_ratio, glm::vec3(color[0], color[1], color[2])));
+        s->flatten();
+        return RT_OK;
+    } catch (const SceneException &e) {
+        return fail(RT_ERR_SCENE, "%s", e.what());
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_NOMEM, "%s", e.what());
+    }
+}
+
+extern "C" int rt_scene_add_light(rt_scene *s, int is_spherical, float intensity, const double v[3], const float color[3])
+{
+    if (!s || !v || !color) return fail(RT_ERR_INVALID, "rt_scene_add_light: null argument");
+    try {
+        const glm::dvec3 dv(v[0], v[1], v[2]);
+        const glm::vec3 c(color[0], color[1], color[2]);
+        s->scene.lights.push_back(is_spherical ? LightSource::spherical(intensity, dv, c) : LightSource::directional(intensity, dv, c));
+        s->flatten();
+        return RT_OK;
+    } catch (const SceneException &e) {
+        return fail(RT_ERR_SCENE, "%s", e.what());
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_NOMEM, "%s", e.what());
+    }
+}
+
+extern "C" int rt_surface_make(int kind, const double a[3], const double b[3], double out_coefs[RT_NCOEF])
+{
+    if (!out_coefs) return fail(RT_ERR_INVALID, "rt_surface_make: null output");
+    if ((kind <= 2 && !a) || (kind <= 1 && !b)) return fail(RT_ERR_INVALID, "rt_surface_make: null argument");
+    try {
+        SurfaceCoefs sc{};
+        switch (kind) {
+        case 0: sc = SurfaceCoefs::sphere(glm::dvec3(a[0], a[1], a[2]), b[0]); break;
+        case 1: sc = SurfaceCoefs::plane(glm::dvec3(a[0], a[1], a[2]), glm::dvec3(b[0], b[1], b[2])); break;
+        case 2: sc = SurfaceCoefs::dingDong(glm::dvec3(a[0], a[1], a[2])); break;
+        case 3: sc = SurfaceCoefs::clebsch(); break;
+        case 4: sc = SurfaceCoefs::cayley(); break;
+        default: return fail(RT_ERR_INVALID, "rt_surface_make: unknown kind %d", kind);
+        }
+        std::memcpy(out_coefs, sc.data(), sizeof(double) * RT_NCOEF);
+        return RT_OK;
+    } catch (const SceneException &e) {
+        return fail(RT_ERR_SCENE, "%s", e.what());
+    }
+}
+
+extern "C" int rt_scene_set_size(rt_scene *s, uint32_t width, uint32_t height)
+{
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_size: null scene");
+    s->scene.px_width = width;
+    s->scene.px_height = height;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_max_reflections(rt_scene *s, uint32_t max_reflections)
+{
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_max_reflections: null scene");
+    s->scene.max_reflections = max_reflections;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_get_desc(const rt_scene *s, rt_scene_desc *out)
+{
+    if (!s || !out) return fail(RT_ERR_INVALID, "rt_scene_get_desc: null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->width = s->scene.px_width;
+    out->height = s->scene.px_height;
+    out->vertical_fov = s->scene.vertical_fov;
+    out->bg_color[0] = s->scene.bg_color.x;
+    out->bg_color[1] = s->scene.bg_color.y;
+    out->bg_color[2] = s->scene.bg_color.z;
+    out->max_reflections = s->scene.max_reflections;
+    out->n_objects = (uint32_t) s->scene.objects.size();
+    out->n_lights = (uint32_t) s->scene.lights.size();
+    out->coefs = s->coefs.data();
+    out->reflection = s->reflection.data();
+    out->albedo = s->albedo.data();
+    out->light_is_spherical = s->light_kind.data();
+    out->light_p = s->light_p.data();
+    out->light_color = s->light_color.data();
+    return RT_OK;
+}
+
+extern "C" void rt_scene_free(rt_scene *s) { delete s; }
+
+// ---- render -------------------------------------------------------------------------------------------
+static uint32_t classify(const double *c)
+{
+    uint32_t cls = 0;
+    for (int i = K_X3; i <= K_XYZ; i++)
+        if (c[i] != 0.0) cls |= RT_CLS_CUBIC;
+    if (cls & RT_CLS_CUBIC) return RT_CLS_CUBIC; // dense path handles everything
+    if (c[K_X2] != 0.0 || c[K_Y2] != 0.0 || c[K_Z2] != 0.0) cls |= RT_CLS_SQUARE;
+    if (c[K_XY] != 0.0 || c[K_XZ] != 0.0 || c[K_YZ] != 0.0) cls |= RT_CLS_CROSS;
+    if (!(cls & RT_CLS_CROSS) && c[K_X2] == 1.0 && c[K_Y2] == 1.0 && c[K_Z2] == 1.0) cls |= RT_CLS_UNITSQ;
+    return cls;
+}
+
+static uint32_t rows_of_rank(uint32_t height, uint32_t band, uint32_t world, uint32_t rank)
+{
+    // bands b = rank, rank + world, ... ; the last band of the image may be partial
+    uint32_t n_bands = (height + band - 1) / band, rows = 0;
+    for (uint32_t b = rank; b < n_bands; b += world) {
+        uint32_t y0 = b * band;
+        rows += (y0 + band <= height) ? band : height - y0;
+    }
+    return rows;
+}
+
+extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config *cfg_in)
+{
+    if (!out || !sd) return fail(RT_ERR_INVALID, "rt_create: null argument");
+    *out = nullptr;
+    rt_config cfg{};
+    cfg.device = -1;
+    cfg.world = 1;
+    if (cfg_in) cfg = *cfg_in;
+    if (cfg.world == 0) cfg.world = 1;
+    if (cfg.band_rows == 0) cfg.band_rows = 8;
+    if (cfg.rank >= cfg.world) return fail(RT_ERR_INVALID, "rt_create: rank %u >= world %u", cfg.rank, cfg.world);
+    if (cfg.format > RT_FMT_RGBA8) return fail(RT_ERR_INVALID, "rt_create: unknown format %u", cfg.format);
+    if (sd->width == 0 || sd->height == 0) return fail(RT_ERR_INVALID, "rt_create: empty image %ux%u", sd->width, sd->height);
+    if ((sd->n_objects && (!sd->coefs || !sd->reflection || !sd->albedo)) ||
+        (sd->n_lights && (!sd->light_is_spherical || !sd->light_p || !sd->light_color)))
+        return fail(RT_ERR_INVALID, "rt_create: null scene array");
+    if ((size_t) sd->n_objects * sizeof(DevObject) > RT_MAX_LDS_SCENE)
+        return fail(RT_ERR_SCENE, "rt_create: %u objects exceed the %u-byte LDS scene budget", sd->n_objects, RT_MAX_LDS_SCENE);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(RT_ERR_NO_DEVICE, "rt_create: no HIP device available (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    int device = cfg.device;
+    if (device < 0) RT_HIP(hipGetDevice(&device));
+    if (device >= ndev) return fail(RT_ERR_INVALID, "rt_create: device %d out of range (%d devices)", device, ndev);
+    RT_HIP(hipSetDevice(device));
+
+    rt_ctx *ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return fail(RT_ERR_NOMEM, "out of memory");
+    ctx->device = device;
+    ctx->cfg = cfg;
+    ctx->pixel_bytes = cfg.format == RT_FMT_RGBA8 ? 4 : 16;
+    ctx->local_rows = rows_of_rank(sd->height, cfg.band_rows, cfg.world, cfg.rank);
+    for (uint32_t r = 0; r < cfg.world; r++) {
+        uint32_t n = rows_of_rank(sd->height, cfg.band_rows, cfg.world, r);
+        if (n > ctx->max_local_rows) ctx->max_local_rows = n;
+    }
+
+    FrameArgs &fa = ctx->fa;
+    std::memset(&fa, 0, sizeof(fa));
+    fa.aspect = (double) sd->width / sd->height;       // Scene::aspect_ratio, include/scene.h:32-33
+    fa.tan_half_fov = std::tan(0.5 * sd->vertical_fov); // init_update, src/update-cpu.cpp:28
+    fa.bg[0] = sd->bg_color[0];
+    fa.bg[1] = sd->bg_color[1];
+    fa.bg[2] = sd->bg_color[2];
+    fa.bg[3] = 1.0f;
+    fa.width = sd->width;
+    fa.height = sd->height;
+    fa.n_obj = sd->n_objects;
+    fa.n_lights = sd->n_lights;
+    fa.max_refl = sd->max_reflections;
+    fa.rank = cfg.rank;
+    fa.world = cfg.world;
+    fa.band_rows = cfg.band_rows;
+    fa.local_rows = ctx->local_rows;
+    fa.tiles_x = (sd->width + RT_TILE - 1) / RT_TILE;
+
+    std::vector<DevObject> objs(sd->n_objects);
+    for (uint32_t i = 0; i < sd->n_objects; i++) {
+        DevObject &o = objs[i];
+        std::memset(&o, 0, sizeof(o));
+        std::memcpy(o.c, sd->coefs + (size_t) i * RT_NCOEF, sizeof(double) * RT_NCOEF);
+        o.albedo[0] = sd->albedo[3 * i + 0];
+        o.albedo[1] = sd->albedo[3 * i + 1];
+        o.albedo[2] = sd->albedo[3 * i + 2];
+        o.refl = sd->reflection[i];
+        o.cls = classify(o.c);
+    }
+    std::vector<DevLight> lights(sd->n_lights);
+    for (uint32_t i = 0; i < sd->n_lights; i++) {
+        DevLight &l = lights[i];
+        std::memset(&l, 0, sizeof(l));
+        for (int k = 0; k < 3; k++) {
+            l.p[k] = sd->light_p[3 * i + k];
+            l.color[k] = sd->light_color[3 * i + k];
+        }
+        l.spherical = sd->light_is_spherical[i] ? 1u : 0u;
+    }
+
+    int rc = RT_OK;
+    auto hip_ok = [&](hipError_t err, const char *what) {
+        if (err != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_DEVICE, "%s failed: %s", what, hipGetErrorString(err));
+        return err == hipSuccess;
+    };
+    const size_t fb_bytes = (size_t) (ctx->local_rows ? ctx->local_rows : 1) * sd->width * ctx->pixel_bytes;
+    hip_ok(hipMalloc((void **) &ctx->d_obj, sizeof(DevObject) * (objs.size() ? objs.size() : 1)), "hipMalloc(objects)") &&
+        hip_ok(hipMalloc((void **) &ctx->d_light, sizeof(DevLight) * (lights.size() ? lights.size() : 1)), "hipMalloc(lights)") &&
+        hip_ok(hipMalloc(&ctx->d_fb, fb_bytes), "hipMalloc(framebuffer)") &&
+        hip_ok(hipMalloc((void **) &ctx->d_counters, sizeof(unsigned long long) * 8), "hipMalloc(counters)") &&
+        hip_ok(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * 8), "hipMemset(counters)") &&
+        hip_ok(objs.empty() ? hipSuccess : hipMemcpy(ctx->d_obj, objs.data(), sizeof(DevObject) * objs.size(), hipMemcpyHostToDevice), "hipMemcpy(objects)") &&
+        hip_ok(lights.empty() ? hipSuccess : hipMemcpy(ctx->d_light, lights.data(), sizeof(DevLight) * lights.size(), hipMemcpyHostToDevice), "hipMemcpy(lights)") &&
+        hip_ok(hipEventCreate(&ctx->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&ctx->ev1), "hipEventCreate");
+    if (rc != RT_OK) {
+        std::string keep = g_last_error;
+        rt_destroy(ctx);
+        g_last_error = keep;
+        return rc;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+extern "C" int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *stream_, float *ms)
+{
+    if (!ctx || !cam) return fail(RT_ERR_INVALID, "rt_render: null argument");
+    hipStream_t stream = (hipStream_t) stream_;
+    FrameArgs &fa = ctx->fa;
+    std::memcpy(fa.cam, cam, sizeof(double) * 16);
+    // g_ray_origin = camera_matrix * (0,0,0,1), src/update-cpu.cpp:123 -- glm order (m0*x + m1*y) + (m2*z + m3*w)
+    for (int r = 0; r < 3; r++) fa.origin[r] = (cam[0 + r] * 0.0 + cam[4 + r] * 0.0) + (cam[8 + r] * 0.0 + cam[12 + r] * 1.0);
+
+    int cur = -1;
+    RT_HIP(hipGetDevice(&cur));
+    if (cur != ctx->device) RT_HIP(hipSetDevice(ctx->device));
+
+    void *fb = dev_fb ? dev_fb : ctx->d_fb;
+    const int count = (ctx->cfg.flags & RT_FLAG_COUNT) ? 1 : 0;
+    const int rgba8 = ctx->cfg.format == RT_FMT_RGBA8;
+    if (count) RT_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * 8, stream));
+    if (ms) RT_HIP(hipEventRecord(ctx->ev0, stream));
+    hipError_t e = (ctx->cfg.flags & RT_FLAG_FAST)
+                       ? rt_launch_trace_fast(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream)
+                       : rt_launch_trace_strict(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    ctx->counted = count != 0;
+    if (ms) {
+        RT_HIP(hipEventRecord(ctx->ev1, stream));
+        RT_HIP(hipEventSynchronize(ctx->ev1));
+        RT_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_local_rows(const rt_ctx *ctx, uint32_t *n_rows)
+{
+    if (!ctx || !n_rows) return fail(RT_ERR_INVALID, "rt_local_rows: null argument");
+    *n_rows = ctx->local_rows;
+    return RT_OK;
+}
+
+extern "C" int rt_max_local_rows(const rt_ctx *ctx, uint32_t *n_rows)
+{
+    if (!ctx || !n_rows) return fail(RT_ERR_INVALID, "rt_max_local_rows: null argument");
+    *n_rows = ctx->max_local_rows;
+    return RT_OK;
+}
+
+extern "C" int rt_row_map(const rt_ctx *ctx, uint32_t *rows)
+{
+    if (!ctx || !rows) return fail(RT_ERR_INVALID, "rt_row_map: null argument");
+    const uint32_t B = ctx->cfg.band_rows, W = ctx->cfg.world, R = ctx->cfg.rank;
+    for (uint32_t lr = 0; lr < ctx->local_rows; lr++) {
+        uint32_t b = lr / B;
+        rows[lr] = (b * W + R) * B + (lr - b * B);
+    }
+    return RT_OK;
+}
+
+extern "C" size_t rt_pixel_bytes(const rt_ctx *ctx) { return ctx ? ctx->pixel_bytes : 0; }
+
+extern "C" void *rt_device_fb(rt_ctx *ctx) { return ctx ? ctx->d_fb : nullptr; }
+
+extern "C" int rt_download(rt_ctx *ctx, void *host_dst, size_t bytes)
+{
+    if (!ctx || !host_dst) return fail(RT_ERR_INVALID, "rt_download: null argument");
+    const size_t have = (size_t) ctx->local_rows * ctx->fa.width * ctx->pixel_bytes;
+    if (bytes > have) return fail(RT_ERR_INVALID, "rt_download: %zu bytes requested, framebuffer holds %zu", bytes, have);
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(host_dst, ctx->d_fb, bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_assemble(rt_ctx *ctx, const void *gathered, void *full, void *stream)
+{
+    if (!ctx || !gathered || !full) return fail(RT_ERR_INVALID, "rt_assemble: null argument");
+    hipError_t e = rt_launch_assemble_strict(gathered, full, ctx->fa.width, ctx->fa.height, ctx->cfg.world, ctx->cfg.band_rows,
+                                             ctx->max_local_rows, ctx->cfg.format == RT_FMT_RGBA8, (hipStream_t) stream);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "assemble launch failed: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+extern "C" int rt_get_counters(rt_ctx *ctx, rt_counters *out)
+{
+    if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_get_counters: null argument");
+    if (!ctx->counted) return fail(RT_ERR_INVALID, "rt_get_counters: the last render was not done with RT_FLAG_COUNT");
+    unsigned long long h[8];
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    out->primary_rays = h[0];
+    out->shadow_rays = h[1];
+    out->reflect_rays = h[2];
+    out->tests = h[3];
+    out->hits = h[4];
+    out->solves = h[5];
+    return RT_OK;
+}
+
+extern "C" int rt_destroy(rt_ctx *ctx)
+{
+    if (!ctx) return RT_OK;
+    (void) hipSetDevice(ctx->device);
+    if (ctx->d_obj) (void) hipFree(ctx->d_obj);
+    if (ctx->d_light) (void) hipFree(ctx->d_light);
+    if (ctx->d_fb) (void) hipFree(ctx->d_fb);
+    if (ctx->d_counters) (void) hipFree(ctx->d_counters);
+    if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
+    delete ctx;
+    return RT_OK;
+}

@@ -1,0 +1,363 @@
+// rt_math.hpp -- per-ray device math of the MI355X ray-tracing path (gfx950, wave64).
+//
+// Included by rt_kernels.hip, which is compiled twice: once with -ffp-contract=off (variant "strict",
+// the parity mode: every FP64/FP32 operation is a separately rounded IEEE operation in the order of the
+// reference's expressions) and once with -ffp-contract=fast (variant "fast": the same expression trees,
+// FMA contraction allowed).
+//
+// What is computed follows the reference (cited per function); HOW is this repo's own:
+//   * per-ray monomials of (origin, dir) are formed once per ray and shared by all objects
+//     (the reference re-derives them inside every intersect_ray call);
+//   * objects are dispatched on a precomputed class (rt_scene_dev.h) so that absent groups of
+//     coefficients cost nothing -- a wave-uniform branch;
+//   * sqrt / division of the quadratic solve are only executed for lanes whose discriminant is
+//     non-negative.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include "rt_scene_dev.h"
+
+namespace rtm {
+
+// include/surface_impl.h:16-19
+constexpr double EPS = 1e-7;
+constexpr double TWO_THIRD_PI = 3.14159265358979323846 * 2.0 / 3.0;
+constexpr double SHADOW_BIAS = 1e-2;
+constexpr double MAX_T = 1e6;
+// (float) M_PIf32, include/light_impl.h:38,43
+constexpr float PI_F = 3.14159274101257324219f;
+
+struct D3 {
+    double x, y, z;
+};
+struct F3 {
+    float x, y, z;
+};
+
+// glm::dot(dvec3): (a.x*b.x + a.y*b.y) + a.z*b.z
+__device__ __forceinline__ double dot3(const D3 &a, const D3 &b)
+{
+    return (a.x * b.x + a.y * b.y) + a.z * b.z;
+}
+
+// glm::normalize(v) = v * (1 / sqrt(dot(v, v)))
+__device__ __forceinline__ D3 normalize3(const D3 &v)
+{
+    double inv = 1.0 / sqrt(dot3(v, v));
+    return D3{v.x * inv, v.y * inv, v.z * inv};
+}
+
+// Monomials of one ray that the degree <= 2 part of F(o + t d) needs.  Names follow the factor each
+// one multiplies in include/surface_impl.h:25-41 (COEF_2, COEF_1_2, COEF_1_11, COEF_0_2).
+struct Mono {
+    D3 o, d;
+    double dxx, dyy, dzz, dxy, dxz, dyz; // d_a d_b
+    double sx, sy, sz;                   // 2 o_a d_a
+    double cxy, cxz, cyz;                // o_a d_b + d_a o_b
+    double oxx, oyy, ozz, oxy, oxz, oyz; // o_a o_b
+    double u2, u1, u0;                   // squared part of t2, t1, t0 for x2 = y2 = z2 = 1
+};
+
+__device__ __forceinline__ void make_mono(Mono &m, const D3 &o, const D3 &d)
+{
+    m.o = o;
+    m.d = d;
+    m.dxx = d.x * d.x;
+    m.dyy = d.y * d.y;
+    m.dzz = d.z * d.z;
+    m.dxy = d.x * d.y;
+    m.dxz = d.x * d.z;
+    m.dyz = d.y * d.z;
+    m.sx = 2.0 * o.x * d.x;
+    m.sy = 2.0 * o.y * d.y;
+    m.sz = 2.0 * o.z * d.z;
+    m.cxy = o.x * d.y + d.x * o.y;
+    m.cxz = o.x * d.z + d.x * o.z;
+    m.cyz = o.y * d.z + d.y * o.z;
+    m.oxx = o.x * o.x;
+    m.oyy = o.y * o.y;
+    m.ozz = o.z * o.z;
+    m.oxy = o.x * o.y;
+    m.oxz = o.x * o.z;
+    m.oyz = o.y * o.z;
+    m.u2 = (m.dxx + m.dyy) + m.dzz;
+    m.u1 = (m.sx + m.sy) + m.sz;
+    m.u0 = (m.oxx + m.oyy) + m.ozz;
+}
+
+// t2, t1, t0 of a surface without degree-3 terms (t3 is an exact zero), include/surface_impl.h:54-103
+// with the zero groups skipped.  `c` may point to global memory (wave-uniform index -> scalar loads) or
+// to LDS (per-lane index).
+__device__ __forceinline__ void quadric_poly(const double *__restrict__ c, uint32_t cls, const Mono &m,
+                                             double &t2, double &t1, double &t0)
+{
+    if (cls & RT_CLS_UNITSQ) {
+        t2 = m.u2;
+        t1 = m.u1;
+        t0 = m.u0;
+    } else if (cls & RT_CLS_SQUARE) {
+        const double x2 = c[K_X2], y2 = c[K_Y2], z2 = c[K_Z2];
+        t2 = (x2 * m.dxx + y2 * m.dyy) + z2 * m.dzz;
+        t1 = (x2 * m.sx + y2 * m.sy) + z2 * m.sz;
+        t0 = (x2 * m.oxx + y2 * m.oyy) + z2 * m.ozz;
+    } else {
+        t2 = 0.0;
+        t1 = 0.0;
+        t0 = 0.0;
+    }
+    if (cls & RT_CLS_CROSS) {
+        const double xy = c[K_XY], xz = c[K_XZ], yz = c[K_YZ];
+        t2 = ((t2 + xy * m.dxy) + xz * m.dxz) + yz * m.dyz;
+        t1 = ((t1 + xy * m.cxy) + xz * m.cxz) + yz * m.cyz;
+        t0 = ((t0 + xy * m.oxy) + xz * m.oxz) + yz * m.oyz;
+    }
+    const double kx = c[K_X], ky = c[K_Y], kz = c[K_Z];
+    t1 = ((t1 + kx * m.d.x) + ky * m.d.y) + kz * m.d.z;
+    t0 = (((t0 + kx * m.o.x) + ky * m.o.y) + kz * m.o.z) + c[K_C];
+}
+
+// Root selection for degree <= 2, include/surface_impl.h:138-154.
+__device__ __forceinline__ double solve_quadlin(double t2, double t1, double t0)
+{
+    if (fabs(t2) > EPS) {
+        double delta = t1 * t1 - 4.0 * t2 * t0;
+        if (delta < 0) return -1.0;
+        delta = sqrt(delta);
+        double x = (-t1 - delta) / (2.0 * t2);
+        if (x >= EPS) return x;
+        return (-t1 + delta) / (2.0 * t2);
+    }
+    if (fabs(t1) > EPS) return -t0 / t1;
+    return -1.0;
+}
+
+// Dense expansion for surfaces with degree-3 terms, include/surface_impl.h:44-103, all 20 terms in the
+// reference's order.  Factor helpers mirror the reference's parenthesisation (argument order matters
+// for rounding).
+__device__ __forceinline__ double tri(double a, double b, double c) { return a * b * c; }
+__device__ __forceinline__ double cube2(double o, double d) { return 3.0 * o * d * d; }
+__device__ __forceinline__ double cube1(double o, double d) { return 3.0 * o * o * d; }
+__device__ __forceinline__ double sqlin2(double op, double dp, double oq, double dq)
+{
+    return dp * (dp * oq + 2.0 * op * dq);
+}
+__device__ __forceinline__ double sqlin1(double op, double dp, double oq, double dq)
+{
+    return op * (op * dq + 2.0 * dp * oq);
+}
+
+__device__ __forceinline__ void cubic_poly(const double *__restrict__ c, const Mono &m, double &t3, double &t2,
+                                           double &t1, double &t0)
+{
+    const double ox = m.o.x, oy = m.o.y, oz = m.o.z, dx = m.d.x, dy = m.d.y, dz = m.d.z;
+    const double x3 = c[K_X3], y3 = c[K_Y3], z3 = c[K_Z3], x2y = c[K_X2Y], xy2 = c[K_XY2], x2z = c[K_X2Z],
+                 xz2 = c[K_XZ2], y2z = c[K_Y2Z], yz2 = c[K_YZ2], xyz = c[K_XYZ];
+    const double x2 = c[K_X2], y2 = c[K_Y2], z2 = c[K_Z2], xy = c[K_XY], xz = c[K_XZ], yz = c[K_YZ];
+    double a;
+    a = x3 * tri(dx, dx, dx);
+    a += y3 * tri(dy, dy, dy);
+    a += z3 * tri(dz, dz, dz);
+    a += x2y * tri(dx, dx, dy);
+    a += xy2 * tri(dx, dy, dy);
+    a += x2z * tri(dx, dx, dz);
+    a += xz2 * tri(dx, dz, dz);
+    a += y2z * tri(dy, dy, dz);
+    a += yz2 * tri(dy, dz, dz);
+    a += xyz * tri(dx, dy, dz);
+    t3 = a;
+    a = x3 * cube2(ox, dx);
+    a += y3 * cube2(oy, dy);
+    a += z3 * cube2(oz, dz);
+    a += x2y * sqlin2(ox, dx, oy, dy);
+    a += xy2 * sqlin2(oy, dy, ox, dx);
+    a += x2z * sqlin2(ox, dx, oz, dz);
+    a += xz2 * sqlin2(oz, dz, ox, dx);
+    a += y2z * sqlin2(oy, dy, oz, dz);
+    a += yz2 * sqlin2(oz, dz, oy, dy);
+    a += xyz * (dx * dy * oz + dx * oy * dz + ox * dy * dz);
+    a += x2 * m.dxx;
+    a += y2 * m.dyy;
+    a += z2 * m.dzz;
+    a += xy * m.dxy;
+    a += xz * m.dxz;
+    a += yz * m.dyz;
+    t2 = a;
+    a = x3 * cube1(ox, dx);
+    a += y3 * cube1(oy, dy);
+    a += z3 * cube1(oz, dz);
+    a += x2y * sqlin1(ox, dx, oy, dy);
+    a += xy2 * sqlin1(oy, dy, ox, dx);
+    a += x2z * sqlin1(ox, dx, oz, dz);
+    a += xz2 * sqlin1(oz, dz, ox, dx);
+    a += y2z * sqlin1(oy, dy, oz, dz);
+    a += yz2 * sqlin1(oz, dz, oy, dy);
+    a += xyz * (dx * oy * oz + ox * dy * oz + ox * oy * dz);
+    a += x2 * m.sx;
+    a += y2 * m.sy;
+    a += z2 * m.sz;
+    a += xy * m.cxy;
+    a += xz * m.cxz;
+    a += yz * m.cyz;
+    a += c[K_X] * dx;
+    a += c[K_Y] * dy;
+    a += c[K_Z] * dz;
+    t1 = a;
+    a = x3 * tri(ox, ox, ox);
+    a += y3 * tri(oy, oy, oy);
+    a += z3 * tri(oz, oz, oz);
+    a += x2y * tri(ox, ox, oy);
+    a += xy2 * tri(ox, oy, oy);
+    a += x2z * tri(ox, ox, oz);
+    a += xz2 * tri(ox, oz, oz);
+    a += y2z * tri(oy, oy, oz);
+    a += yz2 * tri(oy, oz, oz);
+    a += xyz * tri(ox, oy, oz);
+    a += x2 * m.oxx;
+    a += y2 * m.oyy;
+    a += z2 * m.ozz;
+    a += xy * m.oxy;
+    a += xz * m.oxz;
+    a += yz * m.oyz;
+    a += c[K_X] * ox;
+    a += c[K_Y] * oy;
+    a += c[K_Z] * oz;
+    a += c[K_C];
+    t0 = a;
+}
+
+// Cubic root selection, include/surface_impl.h:106-136: Cardano's single real root
+// (unfiltered) or the smallest acceptable of the three trigonometric roots.
+__device__ __forceinline__ double solve_cubic(double t3, double t2, double t1, double t0)
+{
+    t2 /= t3;
+    t1 /= t3;
+    t0 /= t3;
+    double q = (3.0 * t1 - t2 * t2) / 9.0;
+    double r = (9.0 * t2 * t1 - 27.0 * t0 - 2.0 * t2 * t2 * t2) / 54.0;
+    double delta = q * q * q + r * r;
+    if (delta > 0) {
+        delta = sqrt(delta);
+        q = cbrt(r + delta);
+        r = cbrt(r - delta);
+        return q + r - t2 / 3.0;
+    }
+    double theta = acos(r / sqrt(-q * q * q)) / 3.0;
+    double c = 2.0 * sqrt(-q);
+    double x = c * cos(theta) - t2 / 3.0;
+    double x1 = c * cos(theta + TWO_THIRD_PI) - t2 / 3.0;
+    if (x1 >= EPS && x1 < x) x = x1;
+    x1 = c * cos(theta + 2.0 * TWO_THIRD_PI) - t2 / 3.0;
+    if (x1 >= EPS && x1 < x) x = x1;
+    return x;
+}
+
+// Surfaces with degree-3 terms: dense expansion + full solver.  Kept out of line (one copy per kernel)
+// so that the common quadric path stays small in registers; it re-derives the degree <= 2 monomials from
+// (o, d), which is noise next to the ~300 flops and the cbrt/acos/cos of this path.
+__device__ __noinline__ double intersect_cubic(const double *c, double ox, double oy, double oz, double dx, double dy,
+                                               double dz)
+{
+    Mono m;
+    make_mono(m, D3{ox, oy, oz}, D3{dx, dy, dz});
+    double t3, t2, t1, t0;
+    cubic_poly(c, m, t3, t2, t1, t0);
+    if (fabs(t3) > EPS) return solve_cubic(t3, t2, t1, t0);
+    return solve_quadlin(t2, t1, t0);
+}
+
+// intersect_ray, include/surface_impl.h:21-155: parameter of the root the reference would return.
+__device__ __forceinline__ double intersect(const double *__restrict__ c, uint32_t cls, const Mono &m)
+{
+    if (cls & RT_CLS_CUBIC) return intersect_cubic(c, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z);
+    double t2, t1, t0;
+    quadric_poly(c, cls, m, t2, t1, t0);
+    return solve_quadlin(t2, t1, t0);
+}
+
+// normal_vector, include/surface_impl.h:157-172: normalised gradient, never flipped.
+__device__ __forceinline__ D3 normal_vector(const double *__restrict__ c, const D3 &p)
+{
+    D3 g;
+    g.x = ((3.0 * c[K_X3]) * p.x) * p.x + (2.0 * c[K_X2]) * p.x + c[K_X];
+    g.y = ((3.0 * c[K_Y3]) * p.y) * p.y + (2.0 * c[K_Y2]) * p.y + c[K_Y];
+    g.z = ((3.0 * c[K_Z3]) * p.z) * p.z + (2.0 * c[K_Z2]) * p.z + c[K_Z];
+    g.x += 2.0 * p.x * (c[K_X2Y] * p.y + c[K_X2Z] * p.z) + p.y * (c[K_XY2] * p.y + c[K_XYZ] * p.z + c[K_XY])
+           + p.z * (c[K_XZ2] * p.z + c[K_XZ]);
+    g.y += 2.0 * p.y * (c[K_XY2] * p.x + c[K_Y2Z] * p.z) + p.x * (c[K_X2Y] * p.x + c[K_XYZ] * p.z + c[K_XY])
+           + p.z * (c[K_YZ2] * p.z + c[K_YZ]);
+    g.z += 2.0 * p.z * (c[K_XZ2] * p.x + c[K_YZ2] * p.y) + p.x * (c[K_X2Z] * p.x + c[K_XYZ] * p.y + c[K_XZ])
+           + p.y * (c[K_Y2Z] * p.y + c[K_YZ]);
+    return normalize3(g);
+}
+
+// shadow_ray, include/light_impl.h:17-27: the direction passes through FP32.
+__device__ __forceinline__ D3 shadow_dir(const double *__restrict__ lp, bool spherical, const D3 &sp, double &max_t)
+{
+    float fx, fy, fz;
+    if (spherical) {
+        max_t = 1.0;
+        fx = (float) (lp[0] - sp.x);
+        fy = (float) (lp[1] - sp.y);
+        fz = (float) (lp[2] - sp.z);
+    } else {
+        max_t = 1e6;
+        fx = (float) lp[0];
+        fy = (float) lp[1];
+        fz = (float) lp[2];
+    }
+    return D3{(double) fx, (double) fy, (double) fz};
+}
+
+// surface_color, include/light_impl.h:29-44
+__device__ __forceinline__ F3 surface_color(const double *__restrict__ lp, const float *__restrict__ lc,
+                                            bool spherical, const D3 &p, const D3 &n, const F3 &albedo)
+{
+    D3 dir;
+    F3 col;
+    if (spherical) {
+        dir = D3{lp[0] - p.x, lp[1] - p.y, lp[2] - p.z};
+        float denom = 4.0f * PI_F * (float) dot3(dir, dir);
+        col = F3{lc[0] / denom, lc[1] / denom, lc[2] / denom};
+        dir = normalize3(dir);
+    } else {
+        dir = D3{lp[0], lp[1], lp[2]};
+        col = F3{lc[0], lc[1], lc[2]};
+    }
+    float lam = (float) dot3(n, dir);
+    float mx = (0.0f < lam) ? lam : 0.0f; // glm::max(0.0f, lam)
+    return F3{albedo.x / PI_F * col.x * mx, albedo.y / PI_F * col.y * mx, albedo.z / PI_F * col.z * mx};
+}
+
+// reflect_ray, include/light_impl.h:46-49
+__device__ __forceinline__ D3 reflect_ray(const D3 &d, const D3 &n)
+{
+    double s = 2.0 * dot3(d, n);
+    return D3{d.x - s * n.x, d.y - s * n.y, d.z - s * n.z};
+}
+
+// Primary-ray direction of pixel (x, y), src/update-cpu.cpp:84-89.
+__device__ __forceinline__ D3 primary_dir(const FrameArgs &fa, int x, int y)
+{
+    double ndc_x = (x + 0.5) / (int) fa.width;
+    double ndc_y = (y + 0.5) / (int) fa.height;
+    double cx = (2.0 * ndc_x - 1.0) * fa.aspect * fa.tan_half_fov;
+    double cy = (2.0 * ndc_y - 1.0) * fa.tan_half_fov;
+    const double *m = fa.cam;
+    // dmat4 * dvec4(cx, cy, 1, 1): (m0*v.x + m1*v.y) + (m2*v.z + m3*v.w)
+    D3 w;
+    w.x = (m[0] * cx + m[4] * cy) + (m[8] * 1.0 + m[12] * 1.0);
+    w.y = (m[1] * cx + m[5] * cy) + (m[9] * 1.0 + m[13] * 1.0);
+    w.z = (m[2] * cx + m[6] * cy) + (m[10] * 1.0 + m[14] * 1.0);
+    D3 rel{w.x - fa.origin[0], w.y - fa.origin[1], w.z - fa.origin[2]};
+    return normalize3(rel);
+}
+
+// Global image row of local row `lr` under band-cyclic ownership: band b = lr / B of this rank is global
+// band b * world + rank.
+__device__ __forceinline__ uint32_t global_row(const FrameArgs &fa, uint32_t lr)
+{
+    uint32_t b = lr / fa.band_rows;
+    return (b * fa.world + fa.rank) * fa.band_rows + (lr - b * fa.band_rows);
+}
+
+} // namespace rtm

@@ -1,0 +1,161 @@
+/*
+ * mi355rt.h -- C ABI of the MI355X-native per-pixel ray-tracing path (libmi355rt.so).
+ *
+ * This is the drop-in boundary underneath the reference's C++ back-end interface.  The reference
+ * selects a back end at link time by defining three functions (include/update.h:6-8) on top of the
+ * scene model (include/scene.h:8-36) filled by its YAML loader (src/scene.cpp:154-203).  Each entry
+ * point below names the reference interface it replaces; cuda-ray-tracer_amd/host/src/update-hip.cpp
+ * is the adapter that implements update.h on this ABI, INTEGRATION.md shows how a maintainer of
+ * the reference links it.
+ *
+ * Conventions: plain pointers and sizes only, no C++/torch types; every function returns RT_OK (0) or a
+ * negative rt_status and never throws; rt_last_error() gives the message of the calling thread's last
+ * failure.  A context belongs to one thread at a time (the reference back ends keep their state in
+ * file-scope globals, src/update-cpu.cpp:10-19; here it is an explicit object).
+ */
+#ifndef MI355RT_H
+#define MI355RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,   /* bad argument */
+    RT_ERR_SCENE = -2,     /* scene description rejected (what SceneException reports in the reference) */
+    RT_ERR_DEVICE = -3,    /* HIP runtime error */
+    RT_ERR_NO_DEVICE = -4, /* no usable GPU: the product has no CPU fallback */
+    RT_ERR_NOMEM = -5
+} rt_status;
+
+/* Number of doubles per surface: SurfaceCoefs, include/surface.h:10-15, same order
+ * x3 y3 z3 x2y xy2 x2z xz2 y2z yz2 xyz x2 y2 z2 xy xz yz x y z c */
+#define RT_NCOEF 20
+
+/* Flat view of a Scene (include/scene.h:17-36).  Arrays are borrowed for the duration of the call
+ * that receives the descriptor (the reference back ends copy the scene too, src/update-cpu.cpp:29-30). */
+typedef struct rt_scene_desc {
+    uint32_t width, height;        /* Scene::px_width / px_height */
+    double vertical_fov;           /* Scene::vertical_fov, RADIANS */
+    float bg_color[3];             /* Scene::bg_color */
+    uint32_t max_reflections;      /* Scene::max_reflections */
+    uint32_t n_objects;            /* Scene::objects.size() */
+    uint32_t n_lights;             /* Scene::lights.size() */
+    const double *coefs;           /* [n_objects][RT_NCOEF]   Object::surface */
+    const float *reflection;       /* [n_objects]             Object::reflection_ratio */
+    const float *albedo;           /* [n_objects][3]          Object::color */
+    const uint8_t *light_is_spherical; /* [n_lights]          LightSource::is_spherical */
+    const double *light_p;         /* [n_lights][3]           LightSource::p (direction already -normalised) */
+    const float *light_color;      /* [n_lights][3]           LightSource::light_color (intensity folded in) */
+} rt_scene_desc;
+
+/* rt_config.flags */
+#define RT_FLAG_STRICT 0u     /* default: FP64 geometry / FP32 colour with NO FMA contraction -- the arithmetic
+                                 of src/update-cpu.cpp on x86-64; this is the parity mode */
+#define RT_FLAG_FAST 1u       /* same algorithm with FMA contraction allowed (results differ by <=1 ulp per
+                                 operation; pixels on solver discontinuities may flip) */
+#define RT_FLAG_COUNT 2u      /* also count rays / intersection tests on the device (slower; for accounting) */
+
+/* rt_config.format -- framebuffer pixel format */
+#define RT_FMT_RGBA32F 0u     /* 4 x float per pixel, alpha 1.0: the un-quantised colours the CPU back end
+                                 produces (src/update-cpu.cpp:128-131) plus an alpha lane for 16-byte stores */
+#define RT_FMT_RGBA8 1u       /* iround(c*255) RGBA8, alpha 255: the wire format of src/update-cuda.cu:149-156 */
+
+typedef struct rt_config {
+    int32_t device;      /* HIP device ordinal, -1 = the calling thread's current device */
+    uint32_t rank;       /* this context renders the row bands b with b % world == rank */
+    uint32_t world;      /* number of row-band owners (1 = whole frame) */
+    uint32_t band_rows;  /* rows per band, 0 = default (8) */
+    uint32_t flags;      /* RT_FLAG_* */
+    uint32_t format;     /* RT_FMT_* */
+} rt_config;
+
+/* Device-side work counters of the last RT_FLAG_COUNT render (definitions: SURVEY.md 8(d)). */
+typedef struct rt_counters {
+    uint64_t primary_rays;  /* one per pixel */
+    uint64_t shadow_rays;   /* shadow_ray calls: hits x lights (light_impl.h:17) */
+    uint64_t reflect_rays;  /* reflect_ray calls (light_impl.h:46) */
+    uint64_t tests;         /* ray-surface tests = intersect_ray calls in the reference (surface_impl.h:21) */
+    uint64_t hits;          /* nearest-hit records shaded (normal_vector calls, surface_impl.h:157) */
+    uint64_t solves;        /* root solves actually executed by the kernel (<= tests) */
+} rt_counters;
+
+typedef struct rt_ctx rt_ctx;
+typedef struct rt_scene rt_scene;
+
+int rt_abi_version(void);
+const char *rt_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Scene loading -- replaces Scene::load_from_file (include/scene.h:35, src/scene.cpp:154-203) and the
+ * factories it calls (src/surface.cpp:4-60, src/light.cpp:4-26).  Same keys, defaults, validation and
+ * error texts; own YAML-subset parser (yaml-cpp is not a dependency).
+ * ------------------------------------------------------------------------------------------------- */
+int rt_scene_load_file(const char *path, rt_scene **out);
+/* Programmatic construction (Scene::Scene, src/scene.cpp:16-22; fov in DEGREES like the constructor). */
+int rt_scene_new(uint32_t width, uint32_t height, double fov_deg, uint32_t max_reflections,
+                 const float bg_color[3], rt_scene **out);
+/* Object::Object (src/scene.cpp:9-14) with an explicit coefficient vector. */
+int rt_scene_add_object(rt_scene *s, const double coefs[RT_NCOEF], float reflection_ratio, const float color[3]);
+/* LightSource::directional / spherical (src/light.cpp:4-26); v = direction or position. */
+int rt_scene_add_light(rt_scene *s, int is_spherical, float intensity, const double v[3], const float color[3]);
+/* Surface factories, src/surface.cpp:4-60.  kind: 0 sphere(a=center,b[0]=radius) 1 plane(a=origin,b=normal)
+ * 2 dingDong(a=origin) 3 clebsch 4 cayley. */
+int rt_surface_make(int kind, const double a[3], const double b[3], double out_coefs[RT_NCOEF]);
+/* Overrides of the public Scene fields (include/scene.h:19-22); bench configs use resolutions the YAML
+ * files do not contain. */
+int rt_scene_set_size(rt_scene *s, uint32_t width, uint32_t height);
+int rt_scene_set_max_reflections(rt_scene *s, uint32_t max_reflections);
+/* Borrowed view, valid until the scene is modified or freed. */
+int rt_scene_get_desc(const rt_scene *s, rt_scene_desc *out);
+void rt_scene_free(rt_scene *s);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Rendering
+ * ------------------------------------------------------------------------------------------------- */
+/* Replaces init_update (include/update.h:6; src/update-cpu.cpp:22-43, src/update-cuda.cu:34-63):
+ * copies the scene to the device, precomputes aspect and tan(fov/2), allocates the local framebuffer. */
+int rt_create(rt_ctx **out, const rt_scene_desc *scene, const rt_config *cfg);
+
+/* Replaces update (include/update.h:7; src/update-cpu.cpp:121-139, src/update-cuda.cu:160-190).
+ *   cam     camera-to-world dmat4, column-major, 16 doubles (src/ray-tracer.cpp:54-58)
+ *   dev_fb  device pointer receiving this rank's rows ([local_rows][width] pixels of cfg.format), or NULL for
+ *           the context's own offscreen buffer
+ *   stream  hipStream_t to launch on (NULL = default stream)
+ *   ms      if non-NULL: the call synchronises and stores the device time of the render kernels in
+ *           milliseconds (hipEvent pair, what the reference's update() returns); if NULL the call only
+ *           enqueues work (graph-capture safe). */
+int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *stream, float *ms);
+
+/* Row ownership: number of local rows, and for local row i its global y (row 0 = bottom of the image,
+ * src/update-cpu.cpp:125-131).  rt_max_local_rows is the maximum over all ranks (gather stride). */
+int rt_local_rows(const rt_ctx *ctx, uint32_t *n_rows);
+int rt_max_local_rows(const rt_ctx *ctx, uint32_t *n_rows);
+int rt_row_map(const rt_ctx *ctx, uint32_t *rows /* [local_rows] */);
+size_t rt_pixel_bytes(const rt_ctx *ctx);
+
+/* Offscreen buffer of the context (device pointer) and a blocking copy of it to host memory. */
+void *rt_device_fb(rt_ctx *ctx);
+int rt_download(rt_ctx *ctx, void *host_dst, size_t bytes);
+
+/* Root-side reassembly after the gather (the only collective of the path): `gathered` holds
+ * [world][max_local_rows][width] pixels in rank order, `full` receives [height][width] pixels in row order.
+ * Both are device pointers; enqueued on `stream`. */
+int rt_assemble(rt_ctx *ctx, const void *gathered, void *full, void *stream);
+
+/* Counters of the last render done with RT_FLAG_COUNT. */
+int rt_get_counters(rt_ctx *ctx, rt_counters *out);
+
+/* Replaces cleanup_update (include/update.h:8). */
+int rt_destroy(rt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355RT_H */

@@ -1,0 +1,129 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical scene / camera.
+
+Bar (BASELINE.json north_star): every channel within 1e-5 relative of update-cpu.cpp's value.  The strict
+kernel computes the same IEEE operations in the same order as the oracle for surfaces of degree <= 2, so
+there the frames are expected to be BIT-IDENTICAL (asserted); degree-3 surfaces go through device cbrt /
+acos / cos, which differ from glibc's in the last ulp, so they are held to the 1e-5 bar.
+"""
+import numpy as np
+import pytest
+
+from conftest import compare, scene_path
+
+pytestmark = pytest.mark.gpu
+
+QUADRIC = ["quadratic", "20spheres", "reflection_test"]
+CUBIC = ["clebsch", "cubic", "cayley", "dingdong", "monkey_saddle"]
+
+
+def render_gpu(pkg, name, w, h, max_refl=None, cam=None, **kw):
+    sc = pkg.Scene.load_from_file(scene_path(name)).set_size(w, h)
+    if max_refl is not None:
+        sc.set_max_reflections(max_refl)
+    r = pkg.Renderer(sc, device=0, **kw)
+    ms = r.update(cam)
+    img = r.download()
+    cnt = r.counters() if kw.get("flags", 0) & pkg.RT_FLAG_COUNT else None
+    r.cleanup_update()
+    return img, ms, cnt
+
+
+def render_cpu(oracle, name, w, h, max_refl=None, cam=None, counters=False):
+    s = oracle.load_scene(scene_path(name)).with_size(w, h, max_refl)
+    return s.render(cam=cam, counters=counters, nthreads=8)
+
+
+@pytest.mark.parametrize("name", QUADRIC)
+def test_quadric_scenes_bit_identical(pkg, oracle, name):
+    w, h = 320, 240
+    got, _, _ = render_gpu(pkg, name, w, h, 4)
+    want = render_cpu(oracle, name, w, h, 4)
+    assert np.all(got[..., 3] == 1.0)
+    c = compare(got[..., :3], want)
+    assert c["identical"], c
+
+
+@pytest.mark.parametrize("name", CUBIC)
+def test_cubic_scenes_within_tolerance(pkg, oracle, name):
+    w, h = 320, 240
+    got, _, _ = render_gpu(pkg, name, w, h)
+    want = render_cpu(oracle, name, w, h)
+    c = compare(got[..., :3], want)
+    # pixels sitting on a solver discontinuity may flip on a last-ulp difference of cbrt/acos/cos; the
+    # bound is what SURVEY.md section 7 measured between two CPU builds of the reference itself (<= 0.04 % of pixels)
+    assert c["n_bad_pixels"] <= max(2, int(0.0004 * w * h)), c
+
+
+def test_counters_match_oracle(pkg, oracle):
+    w, h = 480, 270
+    for name, mr in (("20spheres", None), ("reflection_test", 4), ("clebsch", None)):
+        _, _, cnt = render_gpu(pkg, name, w, h, mr, flags=pkg.RT_FLAG_COUNT)
+        _, ocnt = render_cpu(oracle, name, w, h, mr, counters=True)
+        for k in ("primary_rays", "shadow_rays", "reflect_rays"):
+            assert cnt[k] == ocnt[k], (name, k, cnt, ocnt)
+        if name != "clebsch":
+            assert cnt["tests"] == ocnt["tests"], (name, cnt, ocnt)
+            assert cnt["hits"] == ocnt["normals"], (name, cnt, ocnt)
+
+
+def test_moved_camera(pkg, oracle):
+    cam = oracle.camera_matrix(pos=(1.5, 2.0, -3.0), yaw_deg=78.0, pitch_deg=9.0)
+    w, h = 256, 192
+    got, _, _ = render_gpu(pkg, "20spheres", w, h, cam=cam)
+    want = render_cpu(oracle, "20spheres", w, h, cam=cam)
+    assert compare(got[..., :3], want)["identical"]
+
+
+def test_band_sharding_reassembles_bit_identical(pkg):
+    """world=3 contexts on one GPU + rt_assemble == the world=1 frame (ragged height: 250 rows, bands of 8)."""
+    import torch
+    w, h, world = 200, 250, 3
+    sc = pkg.Scene.load_from_file(scene_path("20spheres")).set_size(w, h)
+    full = pkg.Renderer(sc, device=0)
+    full.update()
+    want = full.download()
+    rs = [pkg.Renderer(sc, device=0, rank=r, world=world, band_rows=8) for r in range(world)]
+    mx = rs[0].max_local_rows
+    gathered = torch.zeros((world, mx, w, 4), dtype=torch.float32, device="cuda:0")
+    for r, ren in enumerate(rs):
+        assert ren.local_rows == len(pkg.band_rows_of_rank(h, 8, world, r))
+        assert np.array_equal(ren.row_map(), pkg.band_rows_of_rank(h, 8, world, r))
+        ren.update(dev_fb=gathered[r].data_ptr())
+    out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda:0")
+    rs[0].assemble(gathered.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_rgba8_within_one_lsb(pkg, oracle):
+    w, h = 320, 240
+    got, _, _ = render_gpu(pkg, "20spheres", w, h, fmt=pkg.RT_FMT_RGBA8)
+    want = render_cpu(oracle, "20spheres", w, h)
+    q = np.floor(want * 255.0 + 0.5).astype(np.int32)
+    assert got.dtype == np.uint8 and np.all(got[..., 3] == 255)
+    assert np.abs(got[..., :3].astype(np.int32) - q).max() <= 1
+
+
+def test_fast_variant_statistics(pkg, oracle):
+    """FMA-contracted build: same algorithm, <=1 ulp per operation; report (and bound) the flips."""
+    w, h = 320, 240
+    for name in QUADRIC + CUBIC:
+        got, _, _ = render_gpu(pkg, name, w, h, flags=pkg.RT_FLAG_FAST)
+        want = render_cpu(oracle, name, w, h)
+        c = compare(got[..., :3], want)
+        assert c["n_bad_pixels"] <= max(2, int(0.002 * w * h)), (name, c)
+
+
+def test_full_size_properties(pkg, oracle):
+    """BASELINE config 2 at full size: ray counts equal SURVEY.md's table, frame is deterministic, and a
+    sample of rows is bit-identical to the oracle."""
+    w, h = 1920, 1080
+    a, _, cnt = render_gpu(pkg, "20spheres", w, h, flags=pkg.RT_FLAG_COUNT)
+    b, _, _ = render_gpu(pkg, "20spheres", w, h)
+    assert np.array_equal(a, b)
+    assert cnt["rays_total"] == 6754877 and cnt["tests"] == 121254919
+    rows = np.arange(0, h, 37, dtype=np.uint32)
+    want = oracle.load_scene(scene_path("20spheres")).with_size(w, h).render(rows=rows, nthreads=8)
+    assert np.array_equal(a[rows][..., :3], want)
+    # checksum anchor of SURVEY.md 8 work table (sum of all RGB channels in double)
+    assert abs(float(a[..., :3].astype(np.float64).sum()) - 645483.747) < 0.01

@@ -420,6 +420,7 @@ private:
                 pos = skip_spaces(s, pos);
                 if (pos < s.size() && s[pos] == ',') { pos++; continue; }
                 if (pos < s.size() && s[pos] == ']') { pos++; break; }
+                if (pos >= s.size()) fail(m, "unterminated flow sequence");
                 fail(Mark{base.line, base.column + (int) pos}, "expected ',' or ']' in flow sequence");
             }
             return n;
@@ -441,6 +442,7 @@ private:
                 pos = skip_spaces(s, pos);
                 if (pos < s.size() && s[pos] == ',') { pos++; continue; }
                 if (pos < s.size() && s[pos] == '}') { pos++; break; }
+                if (pos >= s.size()) fail(m, "unterminated flow mapping");
                 fail(Mark{base.line, base.column + (int) pos}, "expected ',' or '}' in flow mapping");
             }
             return n;

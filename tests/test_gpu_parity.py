@@ -127,3 +127,61 @@ def test_full_size_properties(pkg, oracle):
     assert np.array_equal(a[rows][..., :3], want)
     # checksum anchor of SURVEY.md 8 work table (sum of all RGB channels in double)
     assert abs(float(a[..., :3].astype(np.float64).sum()) - 645483.747) < 0.01
+
+
+def test_golden_frames(pkg):
+    """HIP path against the committed oracle-rendered fixtures (tests/golden/frames_96x72.npz, two cameras)."""
+    import os
+    from conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "frames_96x72.npz"))
+    for key in g.files:
+        if key.startswith("cam_"):
+            continue
+        name, cam = key.split("__")
+        got, _, _ = render_gpu(pkg, name, 96, 72, cam=g["cam_" + cam])
+        c = compare(got[..., :3], g[key])
+        if name in QUADRIC:
+            assert c["identical"], (key, c)
+        else:
+            assert c["n_bad_pixels"] <= 3, (key, c)
+
+
+@pytest.mark.parametrize("depth", [0, 1, 3, 5])
+def test_reflection_depth_limit(pkg, oracle, depth):
+    """Two facing mirrors: every pixel bounces exactly max_reflections times; none of the
+    reference's scenes reaches the limit, so this one is synthetic."""
+    from test_oracle_units import two_mirror_scene
+    osc = two_mirror_scene(oracle, depth)
+    want, ocnt = osc.render(counters=True)
+    d = pkg.desc_from_arrays(osc.width, osc.height, osc.vertical_fov, osc.bg_color, osc.max_reflections, osc.coefs,
+                             osc.reflection, osc.albedo, osc.light_is_spherical, osc.light_p, osc.light_color)
+    r = pkg.Renderer(d, device=0, flags=pkg.RT_FLAG_COUNT)
+    r.update()
+    got, cnt = r.download(), r.counters()
+    r.cleanup_update()
+    assert cnt["reflect_rays"] == ocnt["reflect_rays"] == depth * osc.width * osc.height
+    assert cnt["tests"] == ocnt["tests"]
+    assert np.array_equal(got[..., :3], want)
+
+
+def test_update_h_drop_in_boundary(pkg, oracle, tmp_path):
+    """A host written only against the reference's update.h / scene.h (tests/host_driver/update_driver.cpp),
+    linked against libmi355rt_update.so, produces the oracle's frame."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "host_driver", "update_driver")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    cam = oracle.camera_matrix(pos=(0.5, 1.0, -2.0), yaw_deg=85.0, pitch_deg=5.0)
+    out = str(tmp_path / "frame.f32")
+    w, h = 200, 150
+    p = subprocess.run([exe, scene_path("reflection_test"), str(w), str(h), "4", out] + [repr(float(v)) for v in cam],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert float(p.stdout.strip()) > 0.0
+    got = np.fromfile(out, dtype=np.float32).reshape(h, w, 4)
+    want = render_cpu(oracle, "reflection_test", w, h, 4, cam=cam)
+    assert np.array_equal(got[..., :3], want) and np.all(got[..., 3] == 1.0)
+    # loader errors surface as the reference's SceneException text on stderr, exit code 1 (src/ray-tracer.cpp:151-158)
+    p = subprocess.run([exe, "/nonexistent.yml", "8", "8", "-1", out], capture_output=True, text=True)
+    assert p.returncode == 1 and "Cannot read the file /nonexistent.yml" in p.stderr

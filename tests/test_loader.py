@@ -1,0 +1,171 @@
+"""The product's scene loader (own YAML-subset parser behind Scene::load_from_file, reached through the C ABI)
+against an independent loader: PyYAML for the syntax + the oracle's factories for the numbers
+(oracle/oracle.py, restating /root/reference/src/scene.cpp:97-201)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, scene_path
+
+ALL = ["quadratic", "20spheres", "reflection_test", "clebsch", "cayley", "cubic", "dingdong", "monkey_saddle"]
+
+
+def same_scene(a, o):
+    assert (a["width"], a["height"], a["max_reflections"]) == (o.width, o.height, o.max_reflections)
+    assert a["vertical_fov"] == o.vertical_fov
+    for k, v in (("bg_color", o.bg_color), ("coefs", o.coefs), ("reflection", o.reflection), ("albedo", o.albedo),
+                 ("light_is_spherical", o.light_is_spherical), ("light_p", o.light_p), ("light_color", o.light_color)):
+        assert np.array_equal(a[k], v), k  # bit-exact: these are parity-critical kernel inputs
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_scene_files_parse_to_identical_values(pkg, oracle, name):
+    same_scene(pkg.Scene.load_from_file(scene_path(name)).arrays(), oracle.load_scene(scene_path(name)))
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_own_scene_files_equal_the_reference_scenes(name):
+    """scenes/*.yml carry the numeric content of /root/reference/scenes/*.yml (only checkable where the
+    reference is mounted)."""
+    import yaml
+    ref = f"/root/reference/scenes/{name}.yml"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present")
+    assert yaml.safe_load(open(ref)) == yaml.safe_load(open(scene_path(name)))
+
+
+SYNTAX = """\
+# leading comment
+---
+width: 64      # trailing comment
+height:   48
+fov: 45.5
+max_reflections: 3
+bg_color: [ 0.25,0.5 , 1 ]
+objects:
+- type: sphere            # dash at the parent's indentation
+  center: [
+     1, 2,
+     30 ]
+  radius: 2.5e0
+  color: [0.1, 0.2, 0.3]
+  reflection_ratio: .5
+-
+  type: "plane"
+  normal: [0, 1, 0]
+  color: [0, 1, 0]
+- {type: polynomial, coefficients: {x2: 1, 'y2': 2.0, z: -3, c: +4}, color: [1, 1, 1]}
+light_sources:
+    - type: spherical
+      position: [0, 10, 0]
+      intensity: 400
+    - type: directional
+      direction: [ 0.4, -0.5, 0.2 ]
+      color: [1, 0.5, 0.25]"""  # no trailing newline, like scenes/reflection_test.yml in the reference
+
+
+def test_syntax_coverage(pkg, oracle, tmp_path):
+    p = tmp_path / "syntax.yml"
+    p.write_text(SYNTAX)
+    a = pkg.Scene.load_from_file(str(p)).arrays()
+    same_scene(a, oracle.load_scene(str(p)))
+    assert a["coefs"].shape == (3, 20) and a["light_p"].shape == (2, 3)
+    assert a["coefs"][2][10] == 1.0 and a["coefs"][2][11] == 2.0 and a["coefs"][2][18] == -3.0 and a["coefs"][2][19] == 4.0
+
+
+def test_defaults(pkg, oracle, tmp_path):
+    """max_reflections 5, bg WHITE, reflection 0, sphere centre 0 / radius 1, plane origin 0 / normal +y,
+    light intensity 1 / colour white (reference src/scene.cpp:6-7,99-151,166-201)."""
+    p = tmp_path / "d.yml"
+    p.write_text("width: 8\nheight: 4\nfov: 90\nobjects:\n  - type: sphere\n    color: [1, 0, 0]\n  - type: plane\n    color: [0, 0, 1]\n"
+                 "light_sources:\n  - type: directional\n    direction: [0, -2, 0]\n")
+    a = pkg.Scene.load_from_file(str(p)).arrays()
+    same_scene(a, oracle.load_scene(str(p)))
+    assert a["max_reflections"] == 5 and np.all(a["bg_color"] == 1.0)
+    assert np.array_equal(a["coefs"][0], pkg.surface_make("sphere", [0, 0, 0], [1.0]))
+    assert np.array_equal(a["coefs"][1], pkg.surface_make("plane", [0, 0, 0], [0, 1, 0]))
+    assert np.array_equal(a["light_p"][0], [0.0, 1.0, 0.0]) and np.all(a["light_color"] == 1.0)
+    # an optional key that does not convert silently keeps its default (yaml-cpp as<T>(fallback) semantics)
+    p.write_text("width: 8\nheight: 4\nfov: 90\nobjects:\n  - type: sphere\n    radius: big\n    color: [1, 0, 0]\nlight_sources: []\n")
+    assert np.array_equal(pkg.Scene.load_from_file(str(p)).arrays()["coefs"][0], pkg.surface_make("sphere", [0, 0, 0], [1.0]))
+
+
+BASE = "width: 8\nheight: 4\nfov: 90\nobjects:\n  - type: sphere\n    color: [1, 0, 0]\nlight_sources:\n  - type: directional\n    direction: [0, -1, 0]\n"
+
+ERRORS = [
+    ("height: 4\nfov: 9\nobjects: []\nlight_sources: []\n", "Value 'width' undefined, line: 1 column: 1"),
+    ("# c\n\nwidth: 8\nfov: 9\nobjects: []\nlight_sources: []\n", "Value 'height' undefined, line: 3 column: 1"),
+    ("width: -8\nheight: 4\nfov: 9\nobjects: []\nlight_sources: []\n", "Value 'width' is invalid, line: 1 column: 8"),
+    ("width: 8\nheight: 4\nfov: wide\nobjects: []\nlight_sources: []\n", "Value 'fov' is invalid, line: 3 column: 6"),
+    ("width: 8\nheight: 4\nfov: 9\nlight_sources: []\n", "Value 'objects' undefined, line: 1 column: 1"),
+    ("width: 8\nheight: 4\nfov: 9\nobjects: 3\nlight_sources: []\n", "Value 'objects' must be a sequence, line: 4 column: 10"),
+    ("width: 8\nheight: 4\nfov: 9\nobjects: []\nlight_sources:\n  a: 1\n", "Value 'light_sources' must be a sequence, line: 6 column: 3"),
+    (BASE.replace("type: sphere", "type: torus"), "Unknown surface type: 'torus', line: 5 column: 11"),
+    (BASE.replace("  - type: sphere\n", "  - radius: 2\n"), "Value 'type' undefined, line: 5 column: 5"),
+    (BASE.replace("    color: [1, 0, 0]\n", ""), "Value 'color' undefined, line: 5 column: 5"),
+    (BASE.replace("color: [1, 0, 0]", "color: [1, 0]"), "Value 'color' is invalid, line: 6 column: 12"),
+    (BASE.replace("color: [1, 0, 0]", "color: [1.5, 0, 0]"), "Invalid color: (1.5, 0, 0)"),
+    (BASE.replace("type: sphere", "type: sphere\n    radius: -1"), "Negative value for sphere radius: -1"),
+    (BASE.replace("color: [1, 0, 0]", "color: [1, 0, 0]\n    reflection_ratio: -0.5"), "Negative value for object reflection ratio: -0.5"),
+    (BASE.replace("type: sphere", "type: polynomial"), "Value 'coefficients' undefined, line: 5 column: 5"),
+    (BASE.replace("type: sphere", "type: polynomial\n    coefficients: 7"), "Value 'coefficients' must be a mapping, line: 6 column: 19"),
+    (BASE.replace("type: directional", "type: laser"), "Light source type must be 'spherical' or 'directional', line: 8 column: 11"),
+    (BASE.replace("    direction: [0, -1, 0]\n", ""), "Value 'direction' undefined, line: 8 column: 5"),
+    (BASE + "    intensity: -2\n", "Negative value for light intensity: -2"),
+    (BASE.replace("fov: 90", "bg_color: [0, 2, 0]\nfov: 90"), "Invalid color: (0, 2, 0)"),
+    ("width: 8\n\theight: 4\n", "YAML parser error: yaml-subset: error at line 2, column 1: tab characters are not allowed as indentation"),
+    ("width: [1, 2\n", "YAML parser error: yaml-subset: error at line 1, column 8: unterminated flow sequence"),
+    ("width: &a 8\n", "YAML parser error: yaml-subset: error at line 1, column 8: unsupported YAML construct '&'"),
+]
+
+
+@pytest.mark.parametrize("text,message", ERRORS, ids=[m[:40] for _, m in ERRORS])
+def test_error_messages(pkg, tmp_path, text, message):
+    """Same wording as the reference's SceneException texts (src/scene.cpp:24-39,64,75,149,199;
+    include/scene-exception.h:31; src/scene-exception.cpp:8).  For the undefined / invalid / must-be cases the
+    independent loader must reject the file too."""
+    p = tmp_path / "bad.yml"
+    p.write_text(text)
+    with pytest.raises(pkg.SceneException) as e:
+        pkg.Scene.load_from_file(str(p))
+    assert e.value.message == message
+
+
+def test_unreadable_file(pkg):
+    with pytest.raises(pkg.SceneException) as e:
+        pkg.Scene.load_from_file("/nonexistent/scene.yml")
+    assert e.value.message == "Cannot read the file /nonexistent/scene.yml"
+
+
+def test_factories_match_oracle(pkg, oracle):
+    """rt_surface_make (host/src/surface.cpp) against the oracle's restatement of src/surface.cpp:4-60."""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    L = oracle.lib()
+    for _ in range(50):
+        a, b = rng.normal(size=3) * 10, rng.normal(size=3)
+        r = abs(rng.normal()) * 3
+        out = (C.c_double * 20)()
+        L.orc_surface_sphere((C.c_double * 3)(*a), r, out)
+        assert np.array_equal(pkg.surface_make("sphere", a, [r]), np.array(out))
+        L.orc_surface_plane((C.c_double * 3)(*a), (C.c_double * 3)(*b), out)
+        assert np.array_equal(pkg.surface_make("plane", a, b), np.array(out))
+        L.orc_surface_dingdong((C.c_double * 3)(*a), out)
+        assert np.array_equal(pkg.surface_make("dingDong", a), np.array(out))
+    L.orc_surface_clebsch(out)
+    cl = pkg.surface_make("clebsch")
+    assert np.array_equal(cl, np.array(out)) and cl[2] == 0.0 and cl[0] == 81.0  # z3 stays 0
+    L.orc_surface_cayley(out)
+    assert np.array_equal(pkg.surface_make("cayley"), np.array(out))
+
+
+def test_programmatic_scene_equals_loaded(pkg):
+    a = pkg.Scene.load_from_file(scene_path("reflection_test")).arrays()
+    s = pkg.Scene.new(600, 450, 30, 5, (0, 0.1, 0.2))
+    s.add_light("directional", [0.8, -0.3, 0.2], (1, 1, 1), 3)
+    s.add_object(pkg.surface_make("sphere", [5, 2, 35], [1]), (0.8, 0.8, 0), 0)
+    s.add_object(pkg.surface_make("plane", [0, -2, 0], [0, 1, 0]), (0, 0.8, 0), 0.3)
+    b = s.arrays()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k

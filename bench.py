@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="config2", help="config2 (default, weak-scaled with --gpus) | config3 | config4 | config5")
     ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
+    ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "wavefront-nocull", "simple"],
+                    help="A/B switch; the product default is the culling wavefront kernel")
     ap.add_argument("--band-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
@@ -108,6 +110,7 @@ def main():
     if max_refl is not None:
         scene.set_max_reflections(max_refl)
     flags = pkg.RT_FLAG_FAST if args.mode == "fast" else pkg.RT_FLAG_STRICT
+    flags |= {"wavefront": 0, "wavefront-nocull": pkg.RT_FLAG_NOCULL, "simple": pkg.RT_FLAG_SIMPLE}[args.kernel]
     band = args.band_rows
     cam = pkg.IDENTITY
 
@@ -189,7 +192,7 @@ def main():
                        "kernel_mode": args.mode, "parallelism": f"rows band-cyclic x{world} (band {band}), gather to rank 0" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "trace_tile_kernel", "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_launch,
+                         "kernel": "trace_tile_kernel" if args.kernel == "simple" else "wavefront_tile_kernel", "kernel_variant": args.kernel, "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_launch,
                          "reference_equivalent_tflops": dense_equiv,
                          "hbm_write_gbs": fb_bytes / (kernel_ms * 1e-3) / 1e9, "hbm_frac": fb_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }

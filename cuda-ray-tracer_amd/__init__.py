@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libmi355rt.so")
 UPDATE_LIB_PATH = os.path.join(_HERE, "libmi355rt_update.so")
 
 RT_NCOEF = 20
-RT_FLAG_STRICT, RT_FLAG_FAST, RT_FLAG_COUNT = 0, 1, 2
+RT_FLAG_STRICT, RT_FLAG_FAST, RT_FLAG_COUNT, RT_FLAG_SIMPLE, RT_FLAG_NOCULL = 0, 1, 2, 4, 8
 RT_FMT_RGBA32F, RT_FMT_RGBA8 = 0, 1
 RT_ERR_NO_DEVICE = -4
 
@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_scene_load_file", "rt_scene_new", "rt_scene_add_object",
     "rt_scene_add_light", "rt_surface_make", "rt_scene_set_size", "rt_scene_set_max_reflections",
     "rt_scene_get_desc", "rt_scene_free", "rt_create", "rt_render", "rt_local_rows", "rt_max_local_rows",
-    "rt_row_map", "rt_pixel_bytes", "rt_device_fb", "rt_download", "rt_assemble", "rt_get_counters", "rt_destroy",
+    "rt_row_map", "rt_pixel_bytes", "rt_device_fb", "rt_download", "rt_assemble", "rt_get_counters", "rt_debug_counters", "rt_destroy",
 ]
 
 
@@ -58,7 +58,7 @@ class Config(C.Structure):
 
 
 class Counters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("primary_rays", "shadow_rays", "reflect_rays", "tests", "hits", "solves")]
+    _fields_ = [(n, C.c_uint64) for n in ("primary_rays", "shadow_rays", "reflect_rays", "tests", "hits", "solves", "tests_executed", "cull_evals")]
 
     def as_dict(self):
         d = {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -119,6 +119,7 @@ def lib():
         L.rt_download.argtypes = [vp, vp, C.c_size_t]
         L.rt_assemble.argtypes = [vp, vp, vp, vp]
         L.rt_get_counters.argtypes = [vp, C.POINTER(Counters)]
+        L.rt_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rt_destroy.argtypes = [vp]
         _lib = L
     return _lib
@@ -302,6 +303,11 @@ class Renderer:
 
     def assemble(self, gathered_ptr, full_ptr, stream=None):
         _check(lib().rt_assemble(self._h, C.c_void_p(gathered_ptr), C.c_void_p(full_ptr), C.c_void_p(stream) if stream else None))
+
+    def debug_counters(self):
+        out = (C.c_uint64 * 32)()
+        _check(lib().rt_debug_counters(self._h, out))
+        return [int(v) for v in out]
 
     def counters(self):
         c = Counters()

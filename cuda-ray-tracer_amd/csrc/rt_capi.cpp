@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -20,6 +21,9 @@
 // kernels, one set per floating-point contraction mode (rt_kernels.hip)
 extern "C" hipError_t rt_launch_trace_strict(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, int, hipStream_t);
 extern "C" hipError_t rt_launch_trace_fast(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, int, hipStream_t);
+extern "C" hipError_t rt_launch_wavefront_strict(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, int, hipStream_t);
+extern "C" hipError_t rt_launch_wavefront_fast(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, int, hipStream_t);
+extern "C" size_t rt_wavefront_lds_bytes_strict(uint32_t, uint32_t, uint32_t);
 extern "C" hipError_t rt_launch_assemble_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 
 namespace {
@@ -92,6 +96,9 @@ struct rt_ctx {
     unsigned long long *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool counted = false;
+    bool zero_counters = false; // diagnostic builds: clear counters[] before every render
+    uint64_t *d_stamps = nullptr;
+    size_t n_stamp_rows = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -323,6 +330,7 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
     fa.tiles_x = (sd->width + RT_TILE - 1) / RT_TILE;
 
     std::vector<DevObject> objs(sd->n_objects);
+    uint32_t n_cullable = 0;
     for (uint32_t i = 0; i < sd->n_objects; i++) {
         DevObject &o = objs[i];
         std::memset(&o, 0, sizeof(o));
@@ -332,7 +340,72 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
         o.albedo[2] = sd->albedo[3 * i + 2];
         o.refl = sd->reflection[i];
         o.cls = classify(o.c);
+        // bounding sphere of a sphere: centre -k/2, r^2 = |centre|^2 - c (src/surface.cpp:4-15 inverted)
+        o.bs_radius = INFINITY;
+        if (o.cls & RT_CLS_UNITSQ) {
+            const double cx = -0.5 * o.c[K_X], cy = -0.5 * o.c[K_Y], cz = -0.5 * o.c[K_Z];
+            const double r2 = cx * cx + cy * cy + cz * cz - o.c[K_C];
+            if (r2 > 0.0 && std::isfinite(r2)) {
+                o.bs_center[0] = cx;
+                o.bs_center[1] = cy;
+                o.bs_center[2] = cz;
+                o.bs_radius = std::sqrt(r2);
+                n_cullable++;
+            }
+        }
     }
+    // culling costs one bounding-volume decision per (object, light, 64-hit chunk); worth it from a handful
+    // of bounded objects upwards
+    fa.cull = (!(cfg.flags & RT_FLAG_NOCULL) && n_cullable >= 4) ? 1u : 0u;
+
+    // per-class tables behind the object array (rt_scene_dev.h)
+    std::vector<UsEntry> t_us;
+    std::vector<GqEntry> t_gq;
+    std::vector<LinEntry> t_lin;
+    std::vector<uint32_t> t_cub;
+    for (uint32_t i = 0; i < sd->n_objects; i++) {
+        const DevObject &o = objs[i];
+        if (o.cls & RT_CLS_CUBIC) {
+            t_cub.push_back(i);
+        } else if (o.cls & RT_CLS_UNITSQ) {
+            UsEntry e{};
+            e.kx = o.c[K_X]; e.ky = o.c[K_Y]; e.kz = o.c[K_Z]; e.c = o.c[K_C];
+            e.r = o.bs_radius;
+            e.inv_r = (o.bs_radius < INFINITY) ? 1.0 / o.bs_radius : 0.0;
+            e.orig = i;
+            t_us.push_back(e);
+        } else if (o.cls & (RT_CLS_SQUARE | RT_CLS_CROSS)) {
+            GqEntry e{};
+            e.x2 = o.c[K_X2]; e.y2 = o.c[K_Y2]; e.z2 = o.c[K_Z2];
+            e.xy = o.c[K_XY]; e.xz = o.c[K_XZ]; e.yz = o.c[K_YZ];
+            e.kx = o.c[K_X]; e.ky = o.c[K_Y]; e.kz = o.c[K_Z]; e.c = o.c[K_C];
+            e.orig = i;
+            t_gq.push_back(e);
+        } else {
+            LinEntry e{};
+            e.kx = o.c[K_X]; e.ky = o.c[K_Y]; e.kz = o.c[K_Z]; e.c = o.c[K_C];
+            e.orig = i;
+            t_lin.push_back(e);
+        }
+    }
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t) 15; };
+    fa.n_us = (uint32_t) t_us.size();
+    fa.n_gq = (uint32_t) t_gq.size();
+    fa.n_lin = (uint32_t) t_lin.size();
+    fa.n_cub = (uint32_t) t_cub.size();
+    fa.n_tab = fa.n_us + fa.n_gq + fa.n_lin;
+    size_t off = up16(sizeof(DevObject) * objs.size());
+    fa.off_us = (uint32_t) off; off = up16(off + sizeof(UsEntry) * t_us.size());
+    fa.off_gq = (uint32_t) off; off = up16(off + sizeof(GqEntry) * t_gq.size());
+    fa.off_lin = (uint32_t) off; off = up16(off + sizeof(LinEntry) * t_lin.size());
+    fa.off_cub = (uint32_t) off; off = up16(off + sizeof(uint32_t) * t_cub.size());
+    fa.scene_bytes = (uint32_t) (off ? off : 16);
+    std::vector<unsigned char> blob(fa.scene_bytes, 0);
+    if (!objs.empty()) std::memcpy(blob.data(), objs.data(), sizeof(DevObject) * objs.size());
+    if (!t_us.empty()) std::memcpy(blob.data() + fa.off_us, t_us.data(), sizeof(UsEntry) * t_us.size());
+    if (!t_gq.empty()) std::memcpy(blob.data() + fa.off_gq, t_gq.data(), sizeof(GqEntry) * t_gq.size());
+    if (!t_lin.empty()) std::memcpy(blob.data() + fa.off_lin, t_lin.data(), sizeof(LinEntry) * t_lin.size());
+    if (!t_cub.empty()) std::memcpy(blob.data() + fa.off_cub, t_cub.data(), sizeof(uint32_t) * t_cub.size());
     std::vector<DevLight> lights(sd->n_lights);
     for (uint32_t i = 0; i < sd->n_lights; i++) {
         DevLight &l = lights[i];
@@ -342,20 +415,35 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
             l.color[k] = sd->light_color[3 * i + k];
         }
         l.spherical = sd->light_is_spherical[i] ? 1u : 0u;
+        for (int k = 0; k < 3; k++) l.sdir[k] = (double) (float) l.p[k];
+        l.dxx = l.sdir[0] * l.sdir[0];
+        l.dyy = l.sdir[1] * l.sdir[1];
+        l.dzz = l.sdir[2] * l.sdir[2];
+        l.dxy = l.sdir[0] * l.sdir[1];
+        l.dxz = l.sdir[0] * l.sdir[2];
+        l.dyz = l.sdir[1] * l.sdir[2];
+        l.u2 = (l.dxx + l.dyy) + l.dzz;
+        l.inv_uu = l.u2 > 0.0 ? 1.0 / l.u2 : 0.0;
+        l.len_u = 1.001 * std::sqrt(l.u2);
     }
 
+    if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.scene_bytes, sd->n_lights, fa.n_tab) > 160u * 1024u) {
+        delete ctx;
+        return fail(RT_ERR_SCENE, "rt_create: scene needs %zu bytes of LDS per workgroup (limit 160 KiB)",
+                    rt_wavefront_lds_bytes_strict(fa.scene_bytes, sd->n_lights, fa.n_tab));
+    }
     int rc = RT_OK;
     auto hip_ok = [&](hipError_t err, const char *what) {
         if (err != hipSuccess && rc == RT_OK) rc = fail(RT_ERR_DEVICE, "%s failed: %s", what, hipGetErrorString(err));
         return err == hipSuccess;
     };
     const size_t fb_bytes = (size_t) (ctx->local_rows ? ctx->local_rows : 1) * sd->width * ctx->pixel_bytes;
-    hip_ok(hipMalloc((void **) &ctx->d_obj, sizeof(DevObject) * (objs.size() ? objs.size() : 1)), "hipMalloc(objects)") &&
+    hip_ok(hipMalloc((void **) &ctx->d_obj, blob.size()), "hipMalloc(scene)") &&
         hip_ok(hipMalloc((void **) &ctx->d_light, sizeof(DevLight) * (lights.size() ? lights.size() : 1)), "hipMalloc(lights)") &&
         hip_ok(hipMalloc(&ctx->d_fb, fb_bytes), "hipMalloc(framebuffer)") &&
-        hip_ok(hipMalloc((void **) &ctx->d_counters, sizeof(unsigned long long) * 8), "hipMalloc(counters)") &&
-        hip_ok(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * 8), "hipMemset(counters)") &&
-        hip_ok(objs.empty() ? hipSuccess : hipMemcpy(ctx->d_obj, objs.data(), sizeof(DevObject) * objs.size(), hipMemcpyHostToDevice), "hipMemcpy(objects)") &&
+        hip_ok(hipMalloc((void **) &ctx->d_counters, sizeof(unsigned long long) * 32), "hipMalloc(counters)") &&
+        hip_ok(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * 32), "hipMemset(counters)") &&
+        hip_ok(hipMemcpy(ctx->d_obj, blob.data(), blob.size(), hipMemcpyHostToDevice), "hipMemcpy(scene)") &&
         hip_ok(lights.empty() ? hipSuccess : hipMemcpy(ctx->d_light, lights.data(), sizeof(DevLight) * lights.size(), hipMemcpyHostToDevice), "hipMemcpy(lights)") &&
         hip_ok(hipEventCreate(&ctx->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&ctx->ev1), "hipEventCreate");
     if (rc != RT_OK) {
@@ -363,6 +451,13 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
         rt_destroy(ctx);
         g_last_error = keep;
         return rc;
+    }
+    ctx->zero_counters = std::getenv("MI355RT_DEBUG_COUNTERS") != nullptr;
+    if (ctx->zero_counters) { // room for the stamp rows of a diagnostic (STAMPS=1) build: one per wave
+        const uint32_t tiles_y = (ctx->local_rows + RT_TILE - 1) / RT_TILE;
+        ctx->n_stamp_rows = (size_t) fa.tiles_x * tiles_y * 4;
+        if (hipMalloc((void **) &ctx->d_stamps, ctx->n_stamp_rows * 12 * sizeof(uint64_t) + 8) != hipSuccess) ctx->d_stamps = nullptr;
+        else (void) hipMemset(ctx->d_stamps, 0, ctx->n_stamp_rows * 12 * sizeof(uint64_t));
     }
     *out = ctx;
     return RT_OK;
@@ -384,11 +479,21 @@ extern "C" int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *
     void *fb = dev_fb ? dev_fb : ctx->d_fb;
     const int count = (ctx->cfg.flags & RT_FLAG_COUNT) ? 1 : 0;
     const int rgba8 = ctx->cfg.format == RT_FMT_RGBA8;
-    if (count) RT_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * 8, stream));
+    if (count || ctx->zero_counters) RT_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * 32, stream));
+    if (ctx->d_stamps) {
+        const unsigned long long ptr = (unsigned long long) (uintptr_t) ctx->d_stamps;
+        RT_HIP(hipMemcpyAsync(ctx->d_counters + 31, &ptr, sizeof(ptr), hipMemcpyHostToDevice, stream));
+        RT_HIP(hipStreamSynchronize(stream));
+    }
     if (ms) RT_HIP(hipEventRecord(ctx->ev0, stream));
-    hipError_t e = (ctx->cfg.flags & RT_FLAG_FAST)
-                       ? rt_launch_trace_fast(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream)
-                       : rt_launch_trace_strict(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream);
+    const bool fast = (ctx->cfg.flags & RT_FLAG_FAST) != 0;
+    hipError_t e;
+    if (ctx->cfg.flags & RT_FLAG_SIMPLE)
+        e = fast ? rt_launch_trace_fast(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream)
+                 : rt_launch_trace_strict(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream);
+    else
+        e = fast ? rt_launch_wavefront_fast(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream)
+                 : rt_launch_wavefront_strict(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream);
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     ctx->counted = count != 0;
     if (ms) {
@@ -462,6 +567,24 @@ extern "C" int rt_get_counters(rt_ctx *ctx, rt_counters *out)
     out->tests = h[3];
     out->hits = h[4];
     out->solves = h[5];
+    out->tests_executed = h[6];
+    out->cull_evals = h[7];
+    return RT_OK;
+}
+
+extern "C" int rt_debug_counters(rt_ctx *ctx, uint64_t out[32])
+{
+    if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_debug_counters: null argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(out, ctx->d_counters, sizeof(uint64_t) * 32, hipMemcpyDeviceToHost));
+    if (ctx->d_stamps) { // diagnostic build: sum the per-wave stamp rows into words 8..19
+        std::vector<uint64_t> rows(ctx->n_stamp_rows * 12);
+        RT_HIP(hipMemcpy(rows.data(), ctx->d_stamps, rows.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 12; i++) out[8 + i] = 0;
+        for (size_t r = 0; r < ctx->n_stamp_rows; r++)
+            for (int i = 0; i < 12; i++) out[8 + i] += rows[r * 12 + i];
+    }
     return RT_OK;
 }
 
@@ -473,6 +596,7 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     if (ctx->d_light) (void) hipFree(ctx->d_light);
     if (ctx->d_fb) (void) hipFree(ctx->d_fb);
     if (ctx->d_counters) (void) hipFree(ctx->d_counters);
+    if (ctx->d_stamps) (void) hipFree(ctx->d_stamps);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     delete ctx;

@@ -34,16 +34,46 @@ struct alignas(16) DevObject {
     float refl;       // Object::reflection_ratio
     uint32_t cls;     // RT_CLS_*
     uint32_t pad[3];
-};                    // 192 B
-static_assert(sizeof(DevObject) == 192, "DevObject layout");
+    // Bounding sphere for the conservative shadow-ray culling of the wavefront kernel (rt_wavefront.hip):
+    // centre and radius of the sphere itself for RT_CLS_UNITSQ objects with a real radius, radius = +inf
+    // ("always test") for everything else.  Derived data, never used to compute a pixel.
+    double bs_center[3];
+    double bs_radius;
+};                    // 224 B
+static_assert(sizeof(DevObject) == 224, "DevObject layout");
+
+// Per-class packed tables for the wavefront kernel's wave-uniform loops (built by rt_create next to the
+// DevObject array, staged into LDS with it).  One entry = exactly the coefficients that class's test reads,
+// so a loop iteration is: one unconditional 16-byte-aligned LDS broadcast read, then arithmetic -- no class
+// word to wait for, no conditional loads.  `orig` is the object's index in the scene (tie-breaking, hit
+// records, counters).
+struct alignas(16) UsEntry {  // RT_CLS_UNITSQ: x2 = y2 = z2 = 1, no cross terms (spheres)
+    double kx, ky, kz, c;     // K_X, K_Y, K_Z, K_C
+    double r, inv_r;          // bounding radius (+inf: do not cull) and 1 / r  -- culling only
+    uint32_t orig, pad[3];
+};                            // 64 B
+struct alignas(16) LinEntry { // no degree-2 terms (planes)
+    double kx, ky, kz, c;
+    uint32_t orig, pad[3];
+};                            // 48 B
+struct alignas(16) GqEntry {  // any other surface of degree <= 2
+    double x2, y2, z2, xy, xz, yz, kx, ky, kz, c;
+    uint32_t orig, pad[3];
+};                            // 96 B
+static_assert(sizeof(UsEntry) == 64 && sizeof(LinEntry) == 48 && sizeof(GqEntry) == 96, "table layout");
 
 struct alignas(16) DevLight {
     double p[3];        // LightSource::p
     float color[3];     // LightSource::light_color
     uint32_t spherical; // LightSource::is_spherical
-    uint32_t pad[2];
-};                      // 48 B
-static_assert(sizeof(DevLight) == 48, "DevLight layout");
+    // Derived at rt_create for the wavefront kernel.  A directional light's shadow rays all use the SAME
+    // direction, the FP32-rounded p (include/light_impl.h:17-27), so its monomials are per-light constants.
+    double sdir[3];                      // (double) (float) p
+    double dxx, dyy, dzz, dxy, dxz, dyz; // products of sdir components (COEF_2 of surface_impl.h:28)
+    double u2;                           // (dxx + dyy) + dzz
+    double inv_uu, len_u;                // 1 / |sdir|^2 and 1.001 |sdir|: culling only
+};                                       // 144 B
+static_assert(sizeof(DevLight) == 144, "DevLight layout");
 
 // Per-launch constants (kernel argument, lands in SGPRs).
 struct FrameArgs {
@@ -58,9 +88,15 @@ struct FrameArgs {
     uint32_t rank, world, band_rows;
     uint32_t local_rows;
     uint32_t tiles_x;    // number of 16-pixel tile columns
+    uint32_t cull;       // wavefront kernel: 1 = cull shadow tests against per-chunk bounding volumes
+    // scene blob = [DevObject x n_obj][UsEntry x n_us][GqEntry x n_gq][LinEntry x n_lin][uint32 x n_cub]
+    uint32_t n_us, n_gq, n_lin, n_cub;
+    uint32_t off_us, off_gq, off_lin, off_cub; // byte offsets into the blob
+    uint32_t scene_bytes;                       // blob size, multiple of 16
+    uint32_t n_tab;                             // n_us + n_gq + n_lin: entries of the primary-ray t0 table
 };
 
-#define RT_TILE 16        // a workgroup renders a 16 x 16 pixel tile: 4 waves of 8 x 8
+#define RT_TILE 16        // a workgroup renders a 16 x 16 pixel tile
 #define RT_MAX_LDS_SCENE (96u * 1024u)
 
 #endif

@@ -1,0 +1,833 @@
+// rt_wavefront.hip -- the production render kernel for gfx950 (MI355X): a workgroup-level wavefront
+// pipeline held entirely in LDS.  Compiled twice like rt_kernels.hip (RT_VARIANT = strict | fast).
+//
+// It computes, pixel for pixel, what the reference's render_pixel / get_color_and_object compute
+// (src/update-cpu.cpp:45-119, through include/surface_impl.h and include/light_impl.h; the
+// reference's GPU twin is update_kernel, src/update-cuda.cu:104-158) -- the arithmetic of every value
+// that reaches a pixel is rt_math.hpp's, shared with the simple kernel.  What differs is the schedule:
+//
+//   one workgroup (4 waves) owns a 16x16 pixel tile and iterates ROUNDS (round 0 = primary rays, round k =
+//   k-th mirror bounce) of five phases separated by workgroup barriers:
+//
+//   A  nearest hit   one lane per live pixel; wave-uniform loop over objects that only forms t2,t1,t0 and the
+//                    sign of the discriminant; the sqrt + divisions of the root solve are DEFERRED to a short
+//                    per-lane loop over the few objects that can hit (a 64-bit candidate mask per lane).
+//                    Hits are compacted into an LDS queue (one LDS atomic per wave, ballot + popcount).
+//   A' per 64-hit chunk: bounding ball of the chunk's hit points (wave min/max reduction); shadow masks zeroed.
+//   B  shadow rays   work item = (light, 64-hit chunk), dealt round-robin to the 4 waves, so a tile with few
+//                    hits still keeps every wave busy.  Per item the wave first CULLS: lane j decides whether
+//                    sphere j can possibly touch any shadow ray of the chunk (distance of its centre to the
+//                    chunk's swept bounding volume, with a generous margin -- purely conservative, see
+//                    relevant_mask); the ballot of that is a wave-uniform object mask.  Then the same
+//                    two-step test as in A over the surviving objects only.  One bit per (hit, light) in LDS.
+//   C  shading       one lane per hit: lights in order, Lambert term for the unshadowed ones, FP32 accumulate,
+//                    clamp (src/update-cpu.cpp:57-78).
+//   D  blend/bounce  the pixel's owner lane blends the colour into its running result and, for mirrors, sets
+//                    up the next round's ray (src/update-cpu.cpp:96-117).
+//
+//   The loop ends when __syncthreads_or says no pixel of the tile is still bouncing; every lane then stores
+//   its pixel (16-byte RGBA32F or 4-byte RGBA8, rows of the tile contiguous).
+//
+// The scene (object records + one packed table per surface class, rt_scene_dev.h) is staged into LDS once per
+// workgroup.  Wave-uniform loops read the class tables with unconditional LDS broadcast reads (LDS returns in
+// order, so unrolled iterations overlap their reads with arithmetic; the first version of this kernel read the
+// object array through scalar loads behind a class branch and spent ~500 cycles per object on serialized
+// s_load round trips -- profiles/r01_*).  Reads with a per-lane index (deferred solves, normals, albedo) gather
+// from the same LDS copy.  Scenes without degree-3 surfaces run an instantiation that contains no cubic code.
+#include <hip/hip_runtime.h>
+
+#include "rt_math.hpp"
+#include "rt_scene_dev.h"
+
+#ifndef RT_VARIANT
+#error "define RT_VARIANT=strict|fast"
+#endif
+#define RT_CAT2(a, b) a##_##b
+#define RT_CAT(a, b) RT_CAT2(a, b)
+#define RT_SYM(name) RT_CAT(name, RT_VARIANT)
+
+namespace RT_SYM(rtw) {
+
+using namespace rtm;
+
+constexpr uint32_t WG = 256; // threads per workgroup = pixels per tile
+
+// Diagnostic build only (make STAMPS=1): per-phase wave-cycle totals into counters[8..], read with
+// rt_debug_counters().  The product build contains no stamp.
+#ifdef RT_WF_STAMPS
+#define RT_STAMP_DECL unsigned long long ph_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long tl_ = clock64();
+#define RT_STAMP(i) do { unsigned long long t_ = clock64(); ph_[i] += t_ - tl_; tl_ = t_; } while (0)
+// one private 12-word row per wave (pointer in counters[31]) -- no atomics, which would distort the timings
+#define RT_STAMP_FLUSH(c, lane) do { if ((lane) == 0) { unsigned long long *row_ = reinterpret_cast<unsigned long long *>((c)[31]) + \
+    ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * 12; for (int i_ = 0; i_ < 12; i_++) row_[i_] = ph_[i_]; } } while (0)
+#else
+#define RT_STAMP_DECL
+#define RT_STAMP(i)
+#define RT_STAMP_FLUSH(c, lane)
+#endif
+#ifndef RT_WF_OCC
+#define RT_WF_OCC 3
+#endif
+
+// counters[]: 0 primary 1 shadow 2 reflect 3 tests (reference-equivalent, valid with cull = 0) 4 hits
+//             5 solves executed 6 tests executed 7 cull evaluations
+template <bool COUNT>
+struct Cnt {
+    __device__ __forceinline__ void add(int, unsigned long long = 1) {}
+    __device__ __forceinline__ void flush(unsigned long long *) {}
+};
+template <>
+struct Cnt<true> {
+    unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __device__ __forceinline__ void add(int i, unsigned long long n = 1) { v[i] += n; }
+    __device__ __forceinline__ void flush(unsigned long long *g)
+    {
+        for (int i = 0; i < 8; i++)
+            if (v[i]) atomicAdd(&g[i], v[i]);
+    }
+};
+
+// Does the reference's solver compute a root for these coefficients (include/surface_impl.h:138-154)?
+// false: it returns -1 without a division (negative discriminant, or a constant polynomial).
+__device__ __forceinline__ bool needs_solve(double t2, double t1, double t0)
+{
+    if (fabs(t2) > EPS) {
+        double delta = t1 * t1 - 4.0 * t2 * t0;
+        return !(delta < 0);
+    }
+    return fabs(t1) > EPS;
+}
+
+// t1 / t0 per class table entry (rt_scene_dev.h).  Same sums as rtm::quadric_poly / include/surface_impl.h:54-103
+// with the exactly-zero groups left out (see RT_CLS_* in rt_scene_dev.h for why that is exact).  t1 and t0 are
+// separate functions because primary rays take t0 from a per-object table (it depends on the origin only).
+__device__ __forceinline__ double us_t1(const UsEntry &e, const Mono &m)
+{
+    return ((m.u1 + e.kx * m.d.x) + e.ky * m.d.y) + e.kz * m.d.z;
+}
+__device__ __forceinline__ double us_t0(const UsEntry &e, const Mono &m)
+{
+    return (((m.u0 + e.kx * m.o.x) + e.ky * m.o.y) + e.kz * m.o.z) + e.c;
+}
+__device__ __forceinline__ double lin_t1(const LinEntry &e, const Mono &m)
+{
+    return (e.kx * m.d.x + e.ky * m.d.y) + e.kz * m.d.z;
+}
+__device__ __forceinline__ double lin_t0(const LinEntry &e, const Mono &m)
+{
+    return ((e.kx * m.o.x + e.ky * m.o.y) + e.kz * m.o.z) + e.c;
+}
+__device__ __forceinline__ double gq_t2(const GqEntry &e, const Mono &m)
+{
+    return ((((e.x2 * m.dxx + e.y2 * m.dyy) + e.z2 * m.dzz) + e.xy * m.dxy) + e.xz * m.dxz) + e.yz * m.dyz;
+}
+__device__ __forceinline__ double gq_t1(const GqEntry &e, const Mono &m)
+{
+    return (((((((e.x2 * m.sx + e.y2 * m.sy) + e.z2 * m.sz) + e.xy * m.cxy) + e.xz * m.cxz) + e.yz * m.cyz) + e.kx * m.d.x) +
+            e.ky * m.d.y) + e.kz * m.d.z;
+}
+__device__ __forceinline__ double gq_t0(const GqEntry &e, const Mono &m)
+{
+    return ((((((((e.x2 * m.oxx + e.y2 * m.oyy) + e.z2 * m.ozz) + e.xy * m.oxy) + e.xz * m.oxz) + e.yz * m.oyz) + e.kx * m.o.x) +
+             e.ky * m.o.y) + e.kz * m.o.z) + e.c;
+}
+
+// Monomials of a ray in three parts, so that a part that is shared (origin of a whole chunk, direction of a
+// directional light) is formed once.  The cross / mixed ones are only formed when some table needs them.
+__device__ __forceinline__ void mono_set_o(Mono &m, const D3 &o, bool need_cross)
+{
+    m.o = o;
+    m.oxx = o.x * o.x;
+    m.oyy = o.y * o.y;
+    m.ozz = o.z * o.z;
+    m.u0 = (m.oxx + m.oyy) + m.ozz;
+    m.oxy = m.oxz = m.oyz = 0.0;
+    if (need_cross) {
+        m.oxy = o.x * o.y;
+        m.oxz = o.x * o.z;
+        m.oyz = o.y * o.z;
+    }
+}
+__device__ __forceinline__ void mono_set_d(Mono &m, const D3 &d, bool need_cross)
+{
+    m.d = d;
+    m.dxx = d.x * d.x;
+    m.dyy = d.y * d.y;
+    m.dzz = d.z * d.z;
+    m.u2 = (m.dxx + m.dyy) + m.dzz;
+    m.dxy = m.dxz = m.dyz = 0.0;
+    if (need_cross) {
+        m.dxy = d.x * d.y;
+        m.dxz = d.x * d.z;
+        m.dyz = d.y * d.z;
+    }
+}
+__device__ __forceinline__ void mono_set_od(Mono &m, bool need_cross)
+{
+    m.sx = 2.0 * m.o.x * m.d.x;
+    m.sy = 2.0 * m.o.y * m.d.y;
+    m.sz = 2.0 * m.o.z * m.d.z;
+    m.u1 = (m.sx + m.sy) + m.sz;
+    m.cxy = m.cxz = m.cyz = 0.0;
+    if (need_cross) {
+        m.cxy = m.o.x * m.d.y + m.d.x * m.o.y;
+        m.cxz = m.o.x * m.d.z + m.d.x * m.o.z;
+        m.cyz = m.o.y * m.d.z + m.d.y * m.o.z;
+    }
+}
+
+// Nearest-hit rule of src/update-cpu.cpp:52-55 made order-independent: strict '<' with ascending object index
+// means the lowest index wins ties.
+__device__ __forceinline__ void accept(double t, int k, double &best_t, int &best)
+{
+    if (t >= EPS && t < MAX_T && (t < best_t || (t == best_t && k < best))) {
+        best_t = t;
+        best = k;
+    }
+}
+
+// The scene as staged in LDS.
+struct SceneLds {
+    const DevObject *obj;
+    const UsEntry *us;
+    const GqEntry *gq;
+    const LinEntry *lin;
+    const uint32_t *cub;
+    const DevLight *light;
+    const double *t0p; // [n_us | n_gq | n_lin] t0 of each table entry for the frame's primary-ray origin
+};
+
+__device__ __forceinline__ double wave_min(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_xor(v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// Conservative culling for primary rays: which unit spheres can ANY of this wave's 64 primary rays hit?
+// All rays leave the camera origin; they lie in the cone of half-angle theta around `axis` (the direction of
+// one central lane), theta = the largest angle between axis and a lane's direction.  A sphere (centre v
+// relative to the origin, radius r) can only be hit if it reaches into that cone; with h = v.axis and
+// rho = distance of the centre from the axis line, rho cos(theta) - h sin(theta) is the signed distance of the
+// centre from the cone's generator line (never larger than its distance to the cone), so the sphere is skipped
+// only when that exceeds r plus a margin (1e-6 relative + the cancellation error of the reference's own t0 for
+// huge coordinates).  Squared form, no sqrt / division.
+__device__ __forceinline__ unsigned long long primary_cone_mask(const UsEntry *us, uint32_t base, uint32_t end, const D3 &org,
+                                                                const D3 &axis, double cos_t, uint32_t lane)
+{
+    bool rel = false;
+    const uint32_t j = base + lane;
+    if (j < end) {
+        const UsEntry e = us[j];
+        const double r = e.r;
+        if (!(r < INFINITY)) {
+            rel = true;
+        } else {
+            const double ccx = -0.5 * e.kx, ccy = -0.5 * e.ky, ccz = -0.5 * e.kz;
+            const double vx = ccx - org.x, vy = ccy - org.y, vz = ccz - org.z;
+            const double vv = vx * vx + vy * vy + vz * vz;
+            const double h = vx * axis.x + vy * axis.y + vz * axis.z;
+            double rho2 = vv - h * h;
+            rho2 = rho2 > 0.0 ? rho2 : 0.0;
+            const double v1 = fabs(vx) + fabs(vy) + fabs(vz);
+            const double s2 = ccx * ccx + ccy * ccy + ccz * ccz + org.x * org.x + org.y * org.y + org.z * org.z;
+            const double c = cos_t * (1.0 - 1e-9);               // a slightly wider cone
+            double sin2 = 1.0 - c * c;
+            sin2 = sin2 > 0.0 ? sin2 : 0.0;
+            const double sn = sqrt(sin2);
+            const double lim = r + 1e-6 * (v1 + r + 1.0) + 1e-12 * (s2 + 1.0) * e.inv_r;
+            const double rhs = lim + h * sn; // need rho * c <= rhs
+            rel = !(rhs < 0.0) && !(rho2 * c * c > rhs * rhs);
+        }
+    }
+    return __ballot(rel);
+}
+
+// Phase A.  PRIMARY: every lane's ray starts at the frame's origin -> t0 comes from the per-object table and
+// the unit spheres are first culled against the wave's ray cone.
+template <bool COUNT, bool HAS_CUBIC, bool PRIMARY>
+__device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj, const Mono &m,
+                                        bool live, uint32_t lane, double &best_t, int &best, Cnt<COUNT> &cnt)
+{
+    best = -1;
+    best_t = INFINITY;
+    const bool quad = fabs(m.u2) > EPS; // unit spheres share t2 = u2: one degree decision per ray
+    const double four_t2 = 4.0 * m.u2;
+    D3 axis{0.0, 0.0, 1.0};
+    double cos_t = 1.0;
+    const bool cone = PRIMARY && fa.cull;
+    if (cone) {
+        axis = D3{__shfl(m.d.x, 40), __shfl(m.d.y, 40), __shfl(m.d.z, 40)}; // lane 40 = pixel (8, 2) of the 16x4 block
+        cos_t = wave_min(dot3(axis, m.d));
+    }
+    for (uint32_t base = 0; base < fa.n_us; base += 64) {
+        const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
+        unsigned long long cand = 0;
+        if (cone) {
+            unsigned long long it = primary_cone_mask(S.us, base, end, m.o, axis, cos_t, lane);
+            if (lane == 0) cnt.add(7, end - base);
+            if (live) cnt.add(6, (unsigned long long) __popcll(it));
+            while (it) { // wave-uniform loop over the spheres that reach into this wave's cone
+                const int b = __builtin_ctzll(it);
+                it &= it - 1;
+                const UsEntry e = S.us[base + b];
+                const double t1 = us_t1(e, m);
+                const double t0 = S.t0p[base + b];
+                const bool need = quad ? !(t1 * t1 - four_t2 * t0 < 0) : (fabs(t1) > EPS);
+                cand |= need ? (1ull << b) : 0ull;
+            }
+        } else {
+            if (live) cnt.add(6, end - base);
+#pragma unroll 4
+            for (uint32_t j = base; j < end; j++) { // wave-uniform: LDS broadcast reads, no branches
+                const UsEntry e = S.us[j];
+                const double t1 = us_t1(e, m);
+                const double t0 = PRIMARY ? S.t0p[j] : us_t0(e, m);
+                const bool need = quad ? !(t1 * t1 - four_t2 * t0 < 0) : (fabs(t1) > EPS);
+                cand |= need ? (1ull << (j - base)) : 0ull;
+            }
+        }
+        if (!live) cand = 0;
+        while (cand) { // per lane: the few spheres whose root must actually be computed
+            const int b = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            const UsEntry e = S.us[base + b]; // LDS gather
+            const double t1 = us_t1(e, m);
+            const double t0 = PRIMARY ? S.t0p[base + b] : us_t0(e, m);
+            const double t = solve_quadlin(m.u2, t1, t0);
+            cnt.add(5);
+            accept(t, (int) e.orig, best_t, best);
+        }
+    }
+    for (uint32_t base = 0; base < fa.n_gq; base += 64) {
+        const uint32_t end = (base + 64 < fa.n_gq) ? base + 64 : fa.n_gq;
+        unsigned long long cand = 0;
+        if (live) cnt.add(6, end - base);
+#pragma unroll 2
+        for (uint32_t j = base; j < end; j++) {
+            const GqEntry e = S.gq[j];
+            const double t0 = PRIMARY ? S.t0p[fa.n_us + j] : gq_t0(e, m);
+            cand |= needs_solve(gq_t2(e, m), gq_t1(e, m), t0) ? (1ull << (j - base)) : 0ull;
+        }
+        if (!live) cand = 0;
+        while (cand) {
+            const int b = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            const GqEntry e = S.gq[base + b];
+            const double t0 = PRIMARY ? S.t0p[fa.n_us + base + b] : gq_t0(e, m);
+            const double t = solve_quadlin(gq_t2(e, m), gq_t1(e, m), t0);
+            cnt.add(5);
+            accept(t, (int) e.orig, best_t, best);
+        }
+    }
+    for (uint32_t j = 0; j < fa.n_lin; j++) { // planes: every lane needs the one division, nothing to defer
+        const LinEntry e = S.lin[j];
+        const double t1 = lin_t1(e, m);
+        const double t0 = PRIMARY ? S.t0p[fa.n_us + fa.n_gq + j] : lin_t0(e, m);
+        const double t = (fabs(t1) > EPS) ? -t0 / t1 : -1.0;
+        if (live) {
+            cnt.add(5);
+            cnt.add(6);
+            accept(t, (int) e.orig, best_t, best);
+        }
+    }
+    if (HAS_CUBIC) {
+        for (uint32_t j = 0; j < fa.n_cub; j++) {
+            const uint32_t k = __builtin_amdgcn_readfirstlane(S.cub[j]);
+            if (live) {
+                const double t = intersect_cubic(gobj[k].c, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z);
+                cnt.add(5);
+                cnt.add(6);
+                accept(t, (int) k, best_t, best);
+            }
+        }
+    }
+}
+
+// Conservative culling for phase B: can unit sphere (base + lane) block ANY shadow ray of this chunk towards
+// this light?  Returns the wave-uniform mask of table entries that must be tested.
+//
+// Every shadow ray of the chunk starts within `ball.R` of `ball.c` (hit point + 1e-2 * unit normal; R already
+// includes that bias) and runs along sdir (directional light: the same FP32-rounded direction for all) or to
+// within 1e-2 + 6e-8|e| of the light position (point light, parameter range (EPS, 1)).  A sphere can only block
+// if the reference's solver finds a root, i.e. if the ray's line (directional) / segment (point light) comes
+// within the sphere's radius of its centre.  By the triangle inequality that requires the centre to be within
+// r + R of the chunk's axis line / segment.  `lim` pads this with a margin that dwarfs every rounding
+// effect involved (1e-6 relative to the distances, plus the cancellation error of the reference's own t0 when
+// coordinates are huge); a larger margin only means a few more objects get tested.  Spheres without a real
+// radius carry r = +inf and are always tested; other classes are never culled.  No division, no sqrt.
+struct Ball {
+    double cx, cy, cz, R;
+};
+
+__device__ __forceinline__ unsigned long long relevant_mask(const UsEntry *us, uint32_t base, uint32_t end, const Ball &ball,
+                                                            const DevLight &lt, uint32_t lane)
+{
+    bool rel = false;
+    const uint32_t j = base + lane;
+    if (j < end) {
+        const UsEntry e = us[j];
+        const double r = e.r;
+        if (!(r < INFINITY)) {
+            rel = true; // +inf (not cullable) or NaN
+        } else {
+            const double ccx = -0.5 * e.kx, ccy = -0.5 * e.ky, ccz = -0.5 * e.kz; // centre (src/surface.cpp:10-12 inverted)
+            const double wx = ccx - ball.cx, wy = ccy - ball.cy, wz = ccz - ball.cz;
+            const double ww = wx * wx + wy * wy + wz * wz;
+            const double w1 = fabs(wx) + fabs(wy) + fabs(wz); // >= |w|
+            const double s2 = ccx * ccx + ccy * ccy + ccz * ccz + ball.cx * ball.cx + ball.cy * ball.cy + ball.cz * ball.cz;
+            if (!lt.spherical) {
+                const double along = wx * lt.sdir[0] + wy * lt.sdir[1] + wz * lt.sdir[2];
+                const double perp2 = ww - along * along * lt.inv_uu;
+                const double lim = r + ball.R + 1e-6 * (w1 + r + ball.R + 1.0) + 1e-12 * (s2 + 1.0) * e.inv_r;
+                // within reach of the axis, and not entirely behind the chunk (roots must be > EPS)
+                rel = !(perp2 > lim * lim) && !(along < -lim * lt.len_u);
+            } else {
+                const double ex = lt.p[0] - ball.cx, ey = lt.p[1] - ball.cy, ez = lt.p[2] - ball.cz;
+                const double ee = ex * ex + ey * ey + ez * ez;
+                const double e1 = fabs(ex) + fabs(ey) + fabs(ez);
+                const double we = wx * ex + wy * ey + wz * ez;
+                const double l2 = lt.p[0] * lt.p[0] + lt.p[1] * lt.p[1] + lt.p[2] * lt.p[2];
+                const double lim = r + ball.R + 1e-6 * (w1 + r + ball.R + e1 + 1.0) + 1e-12 * (s2 + l2 + 1.0) * e.inv_r;
+                const double lim2 = lim * lim;
+                // squared distance of the centre from the segment [ball.c, light]: closest point at parameter
+                // we/ee clamped to [0, 1]; the middle case is compared multiplied through by ee
+                if (!(we > 0.0)) rel = !(ww > lim2);
+                else if (!(we < ee)) rel = !((ww - 2.0 * we) + ee > lim2);
+                else rel = !(ww * ee - we * we > lim2 * ee);
+            }
+        }
+    }
+    return __ballot(rel);
+}
+
+__device__ __forceinline__ void blend(F3 &res, float ratio, const F3 &c)
+{
+    // UPDATE_COLOR, src/update-cpu.cpp:100
+    res.x = (1.0f - ratio) * res.x + ratio * c.x;
+    res.y = (1.0f - ratio) * res.y + ratio * c.y;
+    res.z = (1.0f - ratio) * res.z + ratio * c.z;
+}
+
+__host__ __device__ inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+
+// LDS carve-up (dynamic shared memory), shared by kernel and launcher.
+struct LdsLayout {
+    uint32_t scene, light, t0p, hp, hn, hidx, hpix, color, shadow, ball, misc, total, shadow_words;
+    __host__ __device__ LdsLayout(uint32_t scene_bytes, uint32_t n_lights, uint32_t n_tab)
+    {
+        shadow_words = (n_lights + 31) / 32;
+        if (shadow_words == 0) shadow_words = 1;
+        uint32_t off = 0;
+        scene = off; off = align16(off + scene_bytes);
+        light = off; off = align16(off + n_lights * (uint32_t) sizeof(DevLight));
+        t0p = off; off = align16(off + n_tab * 8);
+        hp = off; off = align16(off + 3 * WG * 8);
+        hn = off; off = align16(off + 3 * WG * 8);
+        hidx = off; off = align16(off + WG * 4);
+        hpix = off; off = align16(off + WG * 4);
+        color = off; off = align16(off + 3 * WG * 4);
+        shadow = off; off = align16(off + WG * shadow_words * 4);
+        ball = off; off = align16(off + 4 * (uint32_t) sizeof(Ball));
+        misc = off; off = align16(off + 16);
+        total = off;
+    }
+};
+
+constexpr int NO_BLOCKER = 0x7fffffff;
+
+// Phase B for one (chunk, light) item: is the lane's shadow ray blocked, and (COUNT builds) by which lowest
+// object index.  `blocker` keeps the lowest blocking index seen; without COUNT any blocker ends the search.
+template <bool COUNT, bool HAS_CUBIC>
+__device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj,
+                                              const Mono &sm, double max_t, bool valid, const Ball &ball, const DevLight &lt,
+                                              uint32_t lane, Cnt<COUNT> &cnt)
+{
+    int blocker = NO_BLOCKER;
+    const bool quad = fabs(sm.u2) > EPS;
+    const double four_t2 = 4.0 * sm.u2;
+    for (uint32_t base = 0; base < fa.n_us; base += 64) {
+        const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
+        unsigned long long cand = 0;
+        if (fa.cull) {
+            unsigned long long it = relevant_mask(S.us, base, end, ball, lt, lane);
+            if (lane == 0) cnt.add(7, end - base);
+            if (valid) cnt.add(6, (unsigned long long) __popcll(it));
+            while (it) { // wave-uniform loop over the spheres that survived the culling
+                const int b = __builtin_ctzll(it);
+                it &= it - 1;
+                const UsEntry e = S.us[base + b];
+                const double t1 = us_t1(e, sm), t0 = us_t0(e, sm);
+                const bool need = quad ? !(t1 * t1 - four_t2 * t0 < 0) : (fabs(t1) > EPS);
+                cand |= need ? (1ull << b) : 0ull;
+            }
+        } else {
+            if (valid) cnt.add(6, end - base);
+#pragma unroll 4
+            for (uint32_t j = base; j < end; j++) {
+                const UsEntry e = S.us[j];
+                const double t1 = us_t1(e, sm), t0 = us_t0(e, sm);
+                const bool need = quad ? !(t1 * t1 - four_t2 * t0 < 0) : (fabs(t1) > EPS);
+                cand |= need ? (1ull << (j - base)) : 0ull;
+            }
+        }
+        if (!valid) cand = 0;
+        while (cand) {
+            const int b = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            const UsEntry e = S.us[base + b];
+            if ((int) e.orig > blocker) continue;
+            const double t = solve_quadlin(sm.u2, us_t1(e, sm), us_t0(e, sm));
+            cnt.add(5);
+            if (t > EPS && t < max_t) { // src/update-cpu.cpp:68
+                blocker = (int) e.orig;
+                if (!COUNT) break;
+            }
+        }
+    }
+    for (uint32_t base = 0; base < fa.n_gq; base += 64) {
+        const uint32_t end = (base + 64 < fa.n_gq) ? base + 64 : fa.n_gq;
+        unsigned long long cand = 0;
+        if (valid) cnt.add(6, end - base);
+#pragma unroll 2
+        for (uint32_t j = base; j < end; j++) {
+            const GqEntry e = S.gq[j];
+            cand |= needs_solve(gq_t2(e, sm), gq_t1(e, sm), gq_t0(e, sm)) ? (1ull << (j - base)) : 0ull;
+        }
+        if (!valid || (!COUNT && blocker != NO_BLOCKER)) cand = 0;
+        while (cand) {
+            const int b = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            const GqEntry e = S.gq[base + b];
+            if ((int) e.orig > blocker) continue;
+            const double t = solve_quadlin(gq_t2(e, sm), gq_t1(e, sm), gq_t0(e, sm));
+            cnt.add(5);
+            if (t > EPS && t < max_t) {
+                blocker = (int) e.orig;
+                if (!COUNT) break;
+            }
+        }
+    }
+    for (uint32_t j = 0; j < fa.n_lin; j++) {
+        const LinEntry e = S.lin[j];
+        const double t1 = lin_t1(e, sm), t0 = lin_t0(e, sm);
+        const double t = (fabs(t1) > EPS) ? -t0 / t1 : -1.0;
+        if (valid) {
+            cnt.add(5);
+            cnt.add(6);
+            if (t > EPS && t < max_t && (int) e.orig < blocker) blocker = (int) e.orig;
+        }
+    }
+    if (HAS_CUBIC) {
+        for (uint32_t j = 0; j < fa.n_cub; j++) {
+            const uint32_t k = __builtin_amdgcn_readfirstlane(S.cub[j]);
+            if (valid && (int) k < blocker && (COUNT || blocker == NO_BLOCKER)) {
+                const double t = intersect_cubic(gobj[k].c, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z);
+                cnt.add(5);
+                cnt.add(6);
+                if (t > EPS && t < max_t) blocker = (int) k;
+            }
+        }
+    }
+    return blocker;
+}
+
+template <bool COUNT, bool RGBA8, bool HAS_CUBIC>
+__global__ __launch_bounds__(256, RT_WF_OCC) void wavefront_tile_kernel(const FrameArgs fa, const unsigned char *__restrict__ gscene,
+                                                              const DevLight *__restrict__ glight, void *__restrict__ fb,
+                                                              unsigned long long *__restrict__ counters)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const LdsLayout L(fa.scene_bytes, fa.n_lights, fa.n_tab);
+    const DevObject *gobj = reinterpret_cast<const DevObject *>(gscene);
+    SceneLds S;
+    S.obj = reinterpret_cast<const DevObject *>(smem + L.scene);
+    S.us = reinterpret_cast<const UsEntry *>(smem + L.scene + fa.off_us);
+    S.gq = reinterpret_cast<const GqEntry *>(smem + L.scene + fa.off_gq);
+    S.lin = reinterpret_cast<const LinEntry *>(smem + L.scene + fa.off_lin);
+    S.cub = reinterpret_cast<const uint32_t *>(smem + L.scene + fa.off_cub);
+    S.light = reinterpret_cast<const DevLight *>(smem + L.light);
+    double *t0p = reinterpret_cast<double *>(smem + L.t0p);
+    S.t0p = t0p;
+    double *hp = reinterpret_cast<double *>(smem + L.hp);   // [3][WG] hit points (SoA: lane-consecutive, conflict-free)
+    double *hn = reinterpret_cast<double *>(smem + L.hn);   // [3][WG] hit normals
+    uint32_t *hidx = reinterpret_cast<uint32_t *>(smem + L.hidx); // object of hit h
+    uint32_t *hpix = reinterpret_cast<uint32_t *>(smem + L.hpix); // owner lane (pixel) of hit h
+    float *scolor = reinterpret_cast<float *>(smem + L.color);    // [3][WG] direct lighting of the pixel's hit this round
+    uint32_t *sshadow = reinterpret_cast<uint32_t *>(smem + L.shadow); // [WG][shadow_words] bit l: light l is blocked
+    Ball *sball = reinterpret_cast<Ball *>(smem + L.ball);
+    uint32_t *s_nhits = reinterpret_cast<uint32_t *>(smem + L.misc);
+
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bool need_cross = (fa.n_gq != 0) || (HAS_CUBIC && fa.n_cub != 0);
+    RT_STAMP_DECL
+    { // stage the scene blob (objects + class tables) and the lights into LDS once per workgroup, 16 B per lane per step
+        const uint4 *src = reinterpret_cast<const uint4 *>(gscene);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem + L.scene);
+        const uint32_t n16 = fa.scene_bytes / 16;
+        for (uint32_t i = tid; i < n16; i += WG) dst[i] = src[i];
+        const uint4 *lsrc = reinterpret_cast<const uint4 *>(glight);
+        uint4 *ldst = reinterpret_cast<uint4 *>(smem + L.light);
+        const uint32_t l16 = fa.n_lights * (uint32_t) (sizeof(DevLight) / 16);
+        for (uint32_t i = tid; i < l16; i += WG) ldst[i] = lsrc[i];
+        if (tid == 0) *s_nhits = 0;
+    }
+    __syncthreads();
+    { // t0 of every table entry for the primary-ray origin (src/update-cpu.cpp:123): the same for all pixels
+        Mono mo;
+        mono_set_o(mo, D3{fa.origin[0], fa.origin[1], fa.origin[2]}, true);
+        for (uint32_t j = tid; j < fa.n_tab; j += WG) {
+            double t0;
+            if (j < fa.n_us) t0 = us_t0(S.us[j], mo);
+            else if (j < fa.n_us + fa.n_gq) t0 = gq_t0(S.gq[j - fa.n_us], mo);
+            else t0 = lin_t0(S.lin[j - fa.n_us - fa.n_gq], mo);
+            t0p[j] = t0;
+        }
+    }
+    __syncthreads();
+    RT_STAMP(0);
+
+    // pixel of this lane: tile row-major, 16 pixels per row -> a wave covers a 16 x 4 block of the tile
+    const uint32_t tile_x = blockIdx.x % fa.tiles_x, tile_y = blockIdx.x / fa.tiles_x;
+    const uint32_t x = tile_x * RT_TILE + (tid & 15), lr = tile_y * RT_TILE + (tid >> 4);
+    const bool inside = x < fa.width && lr < fa.local_rows;
+    // lanes outside the image trace a clamped pixel (keeps the wave's primary cone tight); their result is dropped
+    const uint32_t xc = x < fa.width ? x : fa.width - 1, lrc = lr < fa.local_rows ? lr : fa.local_rows - 1;
+    const uint32_t y = global_row(fa, lrc);
+
+    Cnt<COUNT> cnt;
+    const F3 bg{fa.bg[0], fa.bg[1], fa.bg[2]};
+    F3 res = bg;
+    D3 o{fa.origin[0], fa.origin[1], fa.origin[2]};
+    D3 dir = primary_dir(fa, (int) xc, (int) y);
+    bool live = inside; // this pixel still has a ray to trace
+    bool first = true;
+    float cur_ratio = 1.0f;
+    uint32_t n_refl = 0;
+    if (inside) cnt.add(0);
+
+    RT_STAMP(1);
+    for (;;) {
+        // ---------------- phase A: nearest hit, compaction ----------------
+        double best_t;
+        int best;
+        {
+            Mono m;
+            mono_set_o(m, o, need_cross);
+            mono_set_d(m, dir, need_cross);
+            mono_set_od(m, need_cross);
+            if (first) nearest<COUNT, HAS_CUBIC, true>(fa, S, gobj, m, live, lane, best_t, best, cnt);
+            else nearest<COUNT, HAS_CUBIC, false>(fa, S, gobj, m, live, lane, best_t, best, cnt);
+        }
+        RT_STAMP(2);
+        if (live) cnt.add(3, fa.n_obj);
+        const bool hit = live && best >= 0;
+        D3 sp{0.0, 0.0, 0.0}, sn{0.0, 0.0, 1.0};
+        if (hit) {
+            sp = D3{o.x + best_t * dir.x, o.y + best_t * dir.y, o.z + best_t * dir.z};
+            sn = normal_vector(S.obj[best].c, sp);
+            cnt.add(4);
+        }
+        if (live && !hit) { // the ray leaves the scene (src/update-cpu.cpp:93-95,112-115)
+            if (!first) blend(res, cur_ratio, bg);
+            live = false;
+        }
+        {
+            const unsigned long long hm = __ballot(hit);
+            uint32_t slot0 = 0;
+            if (lane == 0 && hm) slot0 = atomicAdd(s_nhits, (uint32_t) __popcll(hm));
+            slot0 = __shfl(slot0, 0);
+            if (hit) {
+                const uint32_t h = slot0 + (uint32_t) __popcll(hm & ((1ull << lane) - 1ull));
+                hp[h] = sp.x; hp[WG + h] = sp.y; hp[2 * WG + h] = sp.z;
+                hn[h] = sn.x; hn[WG + h] = sn.y; hn[2 * WG + h] = sn.z;
+                hidx[h] = (uint32_t) best;
+                hpix[h] = tid;
+            }
+        }
+        RT_STAMP(3);
+        __syncthreads();
+        RT_STAMP(4);
+        const uint32_t n_hits = *s_nhits;
+        const uint32_t n_chunks = (n_hits + 63) >> 6;
+
+        // ---------------- phase A': chunk bounding balls, clear shadow bits ----------------
+        if (tid < n_hits)
+            for (uint32_t w = 0; w < L.shadow_words; w++) sshadow[tid * L.shadow_words + w] = 0;
+        if (wave < n_chunks) { // wave-uniform
+            const bool v = tid < n_hits;
+            const double px = v ? hp[tid] : 0.0, py = v ? hp[WG + tid] : 0.0, pz = v ? hp[2 * WG + tid] : 0.0;
+            const double lox = wave_min(v ? px : INFINITY), hix = wave_max(v ? px : -INFINITY);
+            const double loy = wave_min(v ? py : INFINITY), hiy = wave_max(v ? py : -INFINITY);
+            const double loz = wave_min(v ? pz : INFINITY), hiz = wave_max(v ? pz : -INFINITY);
+            if (lane == 0) {
+                const double dx = hix - lox, dy = hiy - loy, dz = hiz - loz;
+                Ball b;
+                b.cx = 0.5 * (lox + hix);
+                b.cy = 0.5 * (loy + hiy);
+                b.cz = 0.5 * (loz + hiz);
+                // half diagonal of the box (rounded up) + the 1e-2 shadow bias of the ray origins
+                b.R = 0.5 * sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-9) + 1.01e-2;
+                sball[wave] = b;
+            }
+        }
+        __syncthreads();
+        RT_STAMP(5);
+
+        // ---------------- phase B: shadow rays ----------------
+        // Every wave visits every chunk and takes the lights l == (wave - chunk) mod 4 of it, so the per-chunk
+        // part of the ray (origin, its monomials) is formed once per wave and the lights of a tile with few hits
+        // are still spread over all four waves.
+        for (uint32_t c = 0; c < n_chunks; c++) { // wave-uniform
+            const uint32_t h = c * 64 + lane;
+            const bool valid = h < n_hits;
+            const uint32_t hs = valid ? h : c * 64;
+            const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]};
+            const D3 n{hn[hs], hn[WG + hs], hn[2 * WG + hs]};
+            Mono sm;
+            mono_set_o(sm, D3{p.x + SHADOW_BIAS * n.x, p.y + SHADOW_BIAS * n.y, p.z + SHADOW_BIAS * n.z}, need_cross);
+            const Ball ball = sball[c];
+            for (uint32_t l = (wave + 4u - (c & 3u)) & 3u; l < fa.n_lights; l += 4) {
+                const DevLight &lt = S.light[l]; // wave-uniform LDS reads
+                double max_t;
+                if (lt.spherical) {
+                    // shadow_ray, include/light_impl.h:19-21: (light - point) through FP32
+                    max_t = 1.0;
+                    const D3 sd{(double) (float) (lt.p[0] - p.x), (double) (float) (lt.p[1] - p.y), (double) (float) (lt.p[2] - p.z)};
+                    mono_set_d(sm, sd, need_cross);
+                } else {
+                    // include/light_impl.h:23-25: the per-light constant direction and its monomials
+                    max_t = 1e6;
+                    sm.d = D3{lt.sdir[0], lt.sdir[1], lt.sdir[2]};
+                    sm.dxx = lt.dxx; sm.dyy = lt.dyy; sm.dzz = lt.dzz;
+                    sm.dxy = lt.dxy; sm.dxz = lt.dxz; sm.dyz = lt.dyz;
+                    sm.u2 = lt.u2;
+                }
+                mono_set_od(sm, need_cross);
+                if (valid) cnt.add(1);
+                const int blocker = shadow_blocker<COUNT, HAS_CUBIC>(fa, S, gobj, sm, max_t, valid, ball, lt, lane, cnt);
+                if (valid) {
+                    // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
+                    cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
+                    if (blocker != NO_BLOCKER) atomicOr(&sshadow[h * L.shadow_words + (l >> 5)], 1u << (l & 31));
+                }
+            }
+        }
+        RT_STAMP(6);
+        __syncthreads();
+        RT_STAMP(7);
+
+        // ---------------- phase C: shade each hit, lights in order ----------------
+        if (tid < n_hits) {
+            const uint32_t h = tid;
+            const D3 p{hp[h], hp[WG + h], hp[2 * WG + h]};
+            const D3 n{hn[h], hn[WG + h], hn[2 * WG + h]};
+            const DevObject *ob = &S.obj[hidx[h]];
+            const F3 albedo{ob->albedo[0], ob->albedo[1], ob->albedo[2]};
+            F3 acc{0.0f, 0.0f, 0.0f};
+            for (uint32_t l = 0; l < fa.n_lights; l++) {
+                const bool blocked = (sshadow[h * L.shadow_words + (l >> 5)] >> (l & 31)) & 1u;
+                if (!blocked) {
+                    const DevLight &lt = S.light[l];
+                    F3 col = surface_color(lt.p, lt.color, lt.spherical != 0, p, n, albedo);
+                    acc.x += col.x;
+                    acc.y += col.y;
+                    acc.z += col.z;
+                }
+            }
+            const uint32_t px = hpix[h];
+            scolor[px] = (acc.x < 1.0f) ? acc.x : 1.0f; // glm::min(vec3(1.0f), acc)
+            scolor[WG + px] = (acc.y < 1.0f) ? acc.y : 1.0f;
+            scolor[2 * WG + px] = (acc.z < 1.0f) ? acc.z : 1.0f;
+        }
+        RT_STAMP(8);
+        __syncthreads();
+        if (tid == 0) *s_nhits = 0;
+
+        // ---------------- phase D: blend, set up the bounce ----------------
+        if (hit) {
+            const F3 oc{scolor[tid], scolor[WG + tid], scolor[2 * WG + tid]};
+            if (first) res = oc;
+            else blend(res, cur_ratio, oc);
+            const float refl = S.obj[best].refl;
+            if (!((double) refl > EPS)) {
+                live = false;
+            } else {
+                cur_ratio *= refl;
+                if (n_refl == fa.max_refl) {
+                    blend(res, cur_ratio, bg);
+                    live = false;
+                } else {
+                    n_refl++;
+                    dir = reflect_ray(dir, sn);
+                    cnt.add(2);
+                    o = D3{sp.x + SHADOW_BIAS * sn.x, sp.y + SHADOW_BIAS * sn.y, sp.z + SHADOW_BIAS * sn.z};
+                }
+            }
+        }
+        first = false; // wave-uniform: round 0 is over for everybody
+        const int more = __syncthreads_or(live ? 1 : 0); // also orders the s_nhits reset before the next round
+        RT_STAMP(9);
+        if (!more) break;
+    }
+
+    if (inside) {
+        const size_t pix = (size_t) lr * fa.width + x;
+        if (RGBA8) {
+            uchar4 px;
+            px.x = (unsigned char) (int) (res.x * 255.0f + 0.5f);
+            px.y = (unsigned char) (int) (res.y * 255.0f + 0.5f);
+            px.z = (unsigned char) (int) (res.z * 255.0f + 0.5f);
+            px.w = 255;
+            reinterpret_cast<uchar4 *>(fb)[pix] = px;
+        } else {
+            reinterpret_cast<float4 *>(fb)[pix] = make_float4(res.x, res.y, res.z, 1.0f);
+        }
+    }
+    RT_STAMP(10);
+    RT_STAMP_FLUSH(counters, lane);
+    cnt.flush(counters);
+}
+
+} // namespace RT_SYM(rtw)
+
+extern "C" size_t RT_SYM(rt_wavefront_lds_bytes)(uint32_t scene_bytes, uint32_t n_lights, uint32_t n_tab)
+{
+    return RT_SYM(rtw)::LdsLayout(scene_bytes, n_lights, n_tab).total;
+}
+
+extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const DevObject *gobj, const DevLight *glight,
+                                                   void *fb, unsigned long long *counters, int rgba8, int count,
+                                                   hipStream_t stream)
+{
+    using namespace RT_SYM(rtw);
+    const uint32_t tiles_y = (fa->local_rows + RT_TILE - 1) / RT_TILE;
+    const dim3 grid(fa->tiles_x * tiles_y), block(WG);
+    if (grid.x == 0) return hipSuccess;
+    const size_t lds = LdsLayout(fa->scene_bytes, fa->n_lights, fa->n_tab).total;
+    const unsigned char *gs = reinterpret_cast<const unsigned char *>(gobj);
+    const int sel = (count ? 4 : 0) | (rgba8 ? 2 : 0) | (fa->n_cub ? 1 : 0);
+#define RT_LAUNCH(C, R, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, R, Q>), grid, block, lds, stream, *fa, gs, glight, fb, counters)
+    switch (sel) {
+    case 0: RT_LAUNCH(false, false, false); break;
+    case 1: RT_LAUNCH(false, false, true); break;
+    case 2: RT_LAUNCH(false, true, false); break;
+    case 3: RT_LAUNCH(false, true, true); break;
+    case 4: RT_LAUNCH(true, false, false); break;
+    case 5: RT_LAUNCH(true, false, true); break;
+    case 6: RT_LAUNCH(true, true, false); break;
+    default: RT_LAUNCH(true, true, true); break;
+    }
+#undef RT_LAUNCH
+    return hipGetLastError();
+}

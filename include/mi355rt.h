@@ -61,6 +61,10 @@ typedef struct rt_scene_desc {
 #define RT_FLAG_FAST 1u       /* same algorithm with FMA contraction allowed (results differ by <=1 ulp per
                                  operation; pixels on solver discontinuities may flip) */
 #define RT_FLAG_COUNT 2u      /* also count rays / intersection tests on the device (slower; for accounting) */
+#define RT_FLAG_SIMPLE 4u     /* use the simple one-thread-per-pixel kernel (rt_kernels.hip) instead of the
+                                 workgroup wavefront kernel (rt_wavefront.hip); same results, kept for A/B runs */
+#define RT_FLAG_NOCULL 8u     /* wavefront kernel: test every object for every shadow ray (no bounding-volume
+                                 culling); same results, kept for A/B runs and as a cross-check */
 
 /* rt_config.format -- framebuffer pixel format */
 #define RT_FMT_RGBA32F 0u     /* 4 x float per pixel, alpha 1.0: the un-quantised colours the CPU back end
@@ -83,7 +87,10 @@ typedef struct rt_counters {
     uint64_t reflect_rays;  /* reflect_ray calls (light_impl.h:46) */
     uint64_t tests;         /* ray-surface tests = intersect_ray calls in the reference (surface_impl.h:21) */
     uint64_t hits;          /* nearest-hit records shaded (normal_vector calls, surface_impl.h:157) */
-    uint64_t solves;        /* root solves actually executed by the kernel (<= tests) */
+    uint64_t solves;        /* root solves (sqrt + division, or the cubic solver) actually executed */
+    uint64_t tests_executed; /* t2,t1,t0 evaluations actually executed (differs from `tests`: no early break,
+                                minus culled objects) */
+    uint64_t cull_evals;    /* bounding-sphere culling decisions evaluated (one lane each) */
 } rt_counters;
 
 typedef struct rt_ctx rt_ctx;
@@ -151,6 +158,10 @@ int rt_assemble(rt_ctx *ctx, const void *gathered, void *full, void *stream);
 
 /* Counters of the last render done with RT_FLAG_COUNT. */
 int rt_get_counters(rt_ctx *ctx, rt_counters *out);
+
+/* Diagnostics: the raw device counter block (32 words).  Words 0-7 are rt_counters; words 8+ are per-phase
+ * wave-cycle totals that only a library built with `make STAMPS=1` fills in. */
+int rt_debug_counters(rt_ctx *ctx, uint64_t out[32]);
 
 /* Replaces cleanup_update (include/update.h:8). */
 int rt_destroy(rt_ctx *ctx);

@@ -53,7 +53,7 @@ void init_update(unsigned int texture, const Scene &scene)
     std::vector<uint8_t> kind(nl);
     for (size_t i = 0; i < no; i++) {
         const Object &o = scene.objects[i];
-        const double *c = o.surface.data();
+        const double *c = &o.surface.x3; // 20 packed doubles in SurfaceCoefs order (include/surface.h:12-14)
         for (int k = 0; k < RT_NCOEF; k++) coefs[i * RT_NCOEF + k] = c[k];
         refl[i] = o.reflection_ratio;
         for (int k = 0; k < 3; k++) albedo[3 * i + k] = o.color[k];

@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "wavefront-nocull", "simple"],
                     help="A/B switch; the product default is the culling wavefront kernel")
     ap.add_argument("--band-rows", type=int, default=16)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (the product path). gloo stages the gather through host memory and lets several ranks share "
+                         "one GPU: only for rehearsing the N>1 code path on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     args = ap.parse_args()
@@ -112,11 +115,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-tracing path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collectives' tensors live
 
     pkg = graft.load_package()
     scene_name, W, H, max_refl = workload_for(world, args.workload)
@@ -134,7 +143,7 @@ def main():
     cnt = rc.counters()
     rc.cleanup_update()
     keys = ["primary_rays", "shadow_rays", "reflect_rays", "tests", "hits", "solves", "tests_executed", "cull_evals"]
-    tot = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device=dev)
+    tot = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(tot)
     total = {k: int(v) for k, v in zip(keys, tot.tolist())}
@@ -151,7 +160,11 @@ def main():
     def step():
         ren.update(cam, dev_fb=local.data_ptr(), stream=stream.cuda_stream, timed=False)
         if world > 1:
-            g = pkg.gather_to_root(local, world, rank, gathered=gathered)
+            if args.backend == "nccl":
+                g = pkg.gather_to_root(local, world, rank, gathered=gathered)
+            else:  # rehearsal only: host-staged gather
+                gc = pkg.gather_to_root(local.cpu(), world, rank)
+                g = gathered.copy_(gc) if rank == 0 else None
             if rank == 0:
                 ren.assemble(g.data_ptr(), full.data_ptr(), stream=stream.cuda_stream)
 
@@ -171,7 +184,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -183,6 +196,14 @@ def main():
         kernel_ms = ev_ms / args.steps
     else:
         kernel_ms = float(np.mean([ren.update(cam, dev_fb=local.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(10)]))
+
+    # outside the timed region: the reassembled N-rank frame must equal a single-context render of the same scene
+    frame_check = None
+    if world > 1 and rank == 0 and W * H <= 3840 * 2160:
+        ref = pkg.Renderer(scene, device=local_rank, flags=flags)
+        ref.update(cam)
+        frame_check = bool(np.array_equal(ref.download(), full.cpu().numpy()))
+        ref.cleanup_update()
 
     result = None
     if rank == 0:
@@ -219,6 +240,8 @@ def main():
                          "time_vs_dense_algorithm_at_100pct_fp64_peak": (dense_flops / (FP64_VECTOR_PEAK_TFLOPS * 1e12)) / (dt / args.steps),
                          "hbm_write_gbs": fb_bytes / (kernel_ms * 1e-3) / 1e9, "hbm_frac": fb_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        if frame_check is not None:
+            result["config"]["gathered_frame_identical_to_single_gpu_frame"] = frame_check
         if not args.no_cpu_baseline and world == 1:
             O = graft.load_oracle()
             osc = O.load_scene(os.path.join(ROOT, "scenes", scene_name + ".yml")).with_size(W, H, max_refl)

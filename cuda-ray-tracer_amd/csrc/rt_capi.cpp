@@ -21,8 +21,9 @@
 // kernels, one set per floating-point contraction mode (rt_kernels.hip)
 extern "C" hipError_t rt_launch_trace_strict(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, int, hipStream_t);
 extern "C" hipError_t rt_launch_trace_fast(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, int, hipStream_t);
-extern "C" hipError_t rt_launch_wavefront_strict(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, int, hipStream_t);
-extern "C" hipError_t rt_launch_wavefront_fast(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, int, hipStream_t);
+extern "C" hipError_t rt_launch_wavefront_strict(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, uint32_t, hipStream_t);
+extern "C" hipError_t rt_launch_wavefront_fast(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, uint32_t, hipStream_t);
+extern "C" hipError_t rt_wavefront_blocks_per_cu_strict(uint32_t, uint32_t, uint32_t, int, int, int *);
 extern "C" size_t rt_wavefront_lds_bytes_strict(uint32_t, uint32_t, uint32_t);
 extern "C" hipError_t rt_launch_assemble_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 
@@ -98,6 +99,7 @@ struct rt_ctx {
     bool counted = false;
     bool zero_counters = false; // diagnostic builds: clear counters[] before every render
     uint64_t *d_stamps = nullptr;
+    uint32_t grid_cap = 0; // workgroups the device keeps resident: persistent grid size
     size_t n_stamp_rows = 0;
 };
 
@@ -328,6 +330,8 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
     fa.band_rows = cfg.band_rows;
     fa.local_rows = ctx->local_rows;
     fa.tiles_x = (sd->width + RT_TILE - 1) / RT_TILE;
+    fa.n_tiles = fa.tiles_x * ((ctx->local_rows + RT_TILE - 1) / RT_TILE);
+    fa.rgba8 = cfg.format == RT_FMT_RGBA8 ? 1u : 0u;
 
     std::vector<DevObject> objs(sd->n_objects);
     uint32_t n_cullable = 0;
@@ -452,10 +456,19 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
         g_last_error = keep;
         return rc;
     }
+    {
+        // persistent grid: CUs x workgroups per CU for the instantiation this scene uses
+        hipDeviceProp_t prop;
+        int per_cu = 0;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) prop.multiProcessorCount = 256;
+        if (rt_wavefront_blocks_per_cu_strict(fa.scene_bytes, fa.n_lights, fa.n_tab, fa.n_gq != 0, fa.n_cub != 0, &per_cu) != hipSuccess || per_cu < 1)
+            per_cu = 2;
+        ctx->grid_cap = (uint32_t) prop.multiProcessorCount * (uint32_t) per_cu;
+    }
     ctx->zero_counters = std::getenv("MI355RT_DEBUG_COUNTERS") != nullptr;
     if (ctx->zero_counters) { // room for the stamp rows of a diagnostic (STAMPS=1) build: one per wave
-        const uint32_t tiles_y = (ctx->local_rows + RT_TILE - 1) / RT_TILE;
-        ctx->n_stamp_rows = (size_t) fa.tiles_x * tiles_y * 4;
+        // one row per wave of the largest grid either scheduling mode can launch
+        ctx->n_stamp_rows = (size_t) (fa.n_tiles > ctx->grid_cap ? fa.n_tiles : ctx->grid_cap) * 4;
         if (hipMalloc((void **) &ctx->d_stamps, ctx->n_stamp_rows * 12 * sizeof(uint64_t) + 8) != hipSuccess) ctx->d_stamps = nullptr;
         else (void) hipMemset(ctx->d_stamps, 0, ctx->n_stamp_rows * 12 * sizeof(uint64_t));
     }
@@ -479,7 +492,7 @@ extern "C" int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *
     void *fb = dev_fb ? dev_fb : ctx->d_fb;
     const int count = (ctx->cfg.flags & RT_FLAG_COUNT) ? 1 : 0;
     const int rgba8 = ctx->cfg.format == RT_FMT_RGBA8;
-    if (count || ctx->zero_counters) RT_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * 32, stream));
+    if (count || ctx->zero_counters) RT_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * 28, stream));
     if (ctx->d_stamps) {
         const unsigned long long ptr = (unsigned long long) (uintptr_t) ctx->d_stamps;
         RT_HIP(hipMemcpyAsync(ctx->d_counters + 31, &ptr, sizeof(ptr), hipMemcpyHostToDevice, stream));
@@ -492,8 +505,8 @@ extern "C" int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *
         e = fast ? rt_launch_trace_fast(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream)
                  : rt_launch_trace_strict(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream);
     else
-        e = fast ? rt_launch_wavefront_fast(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream)
-                 : rt_launch_wavefront_strict(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream);
+        e = fast ? rt_launch_wavefront_fast(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, count, ctx->grid_cap, stream)
+                 : rt_launch_wavefront_strict(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, count, ctx->grid_cap, stream);
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     ctx->counted = count != 0;
     if (ms) {

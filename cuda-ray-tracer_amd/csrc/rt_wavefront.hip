@@ -68,6 +68,9 @@ constexpr uint32_t WG = 256; // threads per workgroup = pixels per tile
 #ifndef RT_WF_OCC
 #define RT_WF_OCC 3
 #endif
+#ifndef RT_WF_PERSISTENT
+#define RT_WF_PERSISTENT 0
+#endif
 
 // counters[]: 0 primary 1 shadow 2 reflect 3 tests (reference-equivalent, valid with cull = 0) 4 hits
 //             5 solves executed 6 tests executed 7 cull evaluations
@@ -134,8 +137,10 @@ __device__ __forceinline__ double gq_t0(const GqEntry &e, const Mono &m)
 
 // Monomials of a ray in three parts, so that a part that is shared (origin of a whole chunk, direction of a
 // directional light) is formed once.  The cross / mixed ones are only formed when some table needs them.
-__device__ __forceinline__ void mono_set_o(Mono &m, const D3 &o, bool need_cross)
+template <bool NEED_CROSS>
+__device__ __forceinline__ void mono_set_o(Mono &m, const D3 &o)
 {
+    constexpr bool need_cross = NEED_CROSS;
     m.o = o;
     m.oxx = o.x * o.x;
     m.oyy = o.y * o.y;
@@ -148,8 +153,10 @@ __device__ __forceinline__ void mono_set_o(Mono &m, const D3 &o, bool need_cross
         m.oyz = o.y * o.z;
     }
 }
-__device__ __forceinline__ void mono_set_d(Mono &m, const D3 &d, bool need_cross)
+template <bool NEED_CROSS>
+__device__ __forceinline__ void mono_set_d(Mono &m, const D3 &d)
 {
+    constexpr bool need_cross = NEED_CROSS;
     m.d = d;
     m.dxx = d.x * d.x;
     m.dyy = d.y * d.y;
@@ -162,8 +169,10 @@ __device__ __forceinline__ void mono_set_d(Mono &m, const D3 &d, bool need_cross
         m.dyz = d.y * d.z;
     }
 }
-__device__ __forceinline__ void mono_set_od(Mono &m, bool need_cross)
+template <bool NEED_CROSS>
+__device__ __forceinline__ void mono_set_od(Mono &m)
 {
+    constexpr bool need_cross = NEED_CROSS;
     m.sx = 2.0 * m.o.x * m.d.x;
     m.sy = 2.0 * m.o.y * m.d.y;
     m.sz = 2.0 * m.o.z * m.d.z;
@@ -197,22 +206,45 @@ struct SceneLds {
     const double *t0p; // [n_us | n_gq | n_lin] t0 of each table entry for the frame's primary-ray origin
 };
 
-__device__ __forceinline__ double wave_min(double v)
+// Workgroup barrier for LDS-only communication: release/acquire at workgroup scope on the LDS address space only,
+// so it waits for lgkmcnt (LDS) but not for vmcnt -- outstanding framebuffer stores and the tile-counter atomic
+// stay in flight across it.  (__syncthreads() would also drain vmcnt.)
+__device__ __forceinline__ void lds_barrier()
 {
-    for (int off = 32; off > 0; off >>= 1) {
-        double o = __shfl_xor(v, off);
-        v = o < v ? o : v;
-    }
-    return v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-__device__ __forceinline__ double wave_max(double v)
+
+// Cross-lane helpers.  Reductions run on DPP row operations (VALU latency) instead of ds_bpermute round trips
+// through the LDS crossbar; the result is taken from lane 63 with v_readlane and is wave-uniform.
+__device__ __forceinline__ double readlane_d(double v, int l)
 {
-    for (int off = 32; off > 0; off >>= 1) {
-        double o = __shfl_xor(v, off);
-        v = o > v ? o : v;
-    }
-    return v;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v)
+{
+    // lanes without a valid source (or masked rows) keep their own value: op(v, v) == v for min / max
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+#define RT_WAVE_REDUCE(OP)                                                     \
+    {                                                                          \
+        double t;                                                              \
+        t = dpp_d<0xB1, 0xf>(v); v = OP; /* quad_perm [1,0,3,2] */           \
+        t = dpp_d<0x4E, 0xf>(v); v = OP; /* quad_perm [2,3,0,1] */           \
+        t = dpp_d<0x124, 0xf>(v); v = OP; /* row_ror:4 */                    \
+        t = dpp_d<0x128, 0xf>(v); v = OP; /* row_ror:8: every lane has its row of 16 */ \
+        t = dpp_d<0x142, 0xa>(v); v = OP; /* row_bcast:15 into rows 1, 3 */  \
+        t = dpp_d<0x143, 0xc>(v); v = OP; /* row_bcast:31 into rows 2, 3 */  \
+        return readlane_d(v, 63);                                              \
+    }
+__device__ __forceinline__ double wave_min(double v) RT_WAVE_REDUCE((t < v ? t : v))
+__device__ __forceinline__ double wave_max(double v) RT_WAVE_REDUCE((t > v ? t : v))
+#undef RT_WAVE_REDUCE
 
 // Conservative culling for primary rays: which unit spheres can ANY of this wave's 64 primary rays hit?
 // All rays leave the camera origin; they lie in the cone of half-angle theta around `axis` (the direction of
@@ -255,7 +287,7 @@ __device__ __forceinline__ unsigned long long primary_cone_mask(const UsEntry *u
 
 // Phase A.  PRIMARY: every lane's ray starts at the frame's origin -> t0 comes from the per-object table and
 // the unit spheres are first culled against the wave's ray cone.
-template <bool COUNT, bool HAS_CUBIC, bool PRIMARY>
+template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool PRIMARY>
 __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj, const Mono &m,
                                         bool live, uint32_t lane, double &best_t, int &best, Cnt<COUNT> &cnt)
 {
@@ -267,8 +299,14 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
     double cos_t = 1.0;
     const bool cone = PRIMARY && fa.cull;
     if (cone) {
-        axis = D3{__shfl(m.d.x, 40), __shfl(m.d.y, 40), __shfl(m.d.z, 40)}; // lane 40 = pixel (8, 2) of the 16x4 block
-        cos_t = wave_min(dot3(axis, m.d));
+        // axis = direction of lane 40 (pixel (8, 2) of the wave's 16x4 block).  The angle to the axis is a
+        // quasi-convex function on the image plane, so over the block it peaks at one of the four corner pixels
+        // (lanes 0, 15, 48, 63): four v_readlane pairs instead of a 64-lane reduction.
+        axis = D3{readlane_d(m.d.x, 40), readlane_d(m.d.y, 40), readlane_d(m.d.z, 40)};
+        const double ca = dot3(axis, m.d);
+        const double c0 = readlane_d(ca, 0), c1 = readlane_d(ca, 15), c2 = readlane_d(ca, 48), c3 = readlane_d(ca, 63);
+        const double m01 = c0 < c1 ? c0 : c1, m23 = c2 < c3 ? c2 : c3;
+        cos_t = m01 < m23 ? m01 : m23;
     }
     for (uint32_t base = 0; base < fa.n_us; base += 64) {
         const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
@@ -309,7 +347,7 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
             accept(t, (int) e.orig, best_t, best);
         }
     }
-    for (uint32_t base = 0; base < fa.n_gq; base += 64) {
+    for (uint32_t base = 0; HAS_GQ && base < fa.n_gq; base += 64) {
         const uint32_t end = (base + 64 < fa.n_gq) ? base + 64 : fa.n_gq;
         unsigned long long cand = 0;
         if (live) cnt.add(6, end - base);
@@ -411,6 +449,56 @@ __device__ __forceinline__ unsigned long long relevant_mask(const UsEntry *us, u
     return __ballot(rel);
 }
 
+// The light-independent half of relevant_mask for the first 64 spheres, formed ONCE per chunk: lane j keeps
+// sphere j's offset from the chunk's ball and its limit; per light only the projection on the light axis is left.
+struct CullPre {
+    double wx, wy, wz, ww; // centre - ball centre, its squared length
+    double lim, inv_r;     // limit for directional lights; 1/r for the point-light margin term
+    bool always, in_range; // not cullable (r = +inf / NaN); lane < n_us
+};
+
+__device__ __forceinline__ CullPre cull_prepare(const UsEntry *us, uint32_t n_us, const Ball &ball, uint32_t lane)
+{
+    CullPre c;
+    c.in_range = lane < n_us;
+    const UsEntry e = us[c.in_range ? lane : 0];
+    const double r = e.r;
+    c.always = !(r < INFINITY);
+    const double ccx = -0.5 * e.kx, ccy = -0.5 * e.ky, ccz = -0.5 * e.kz;
+    c.wx = ccx - ball.cx;
+    c.wy = ccy - ball.cy;
+    c.wz = ccz - ball.cz;
+    c.ww = c.wx * c.wx + c.wy * c.wy + c.wz * c.wz;
+    const double w1 = fabs(c.wx) + fabs(c.wy) + fabs(c.wz);
+    const double s2 = ccx * ccx + ccy * ccy + ccz * ccz + ball.cx * ball.cx + ball.cy * ball.cy + ball.cz * ball.cz;
+    c.inv_r = e.inv_r;
+    c.lim = r + ball.R + 1e-6 * (w1 + r + ball.R + 1.0) + 1e-12 * (s2 + 1.0) * e.inv_r;
+    return c;
+}
+
+// Same decision as relevant_mask(us, 0, min(n_us, 64), ...) from the prepared half.
+__device__ __forceinline__ unsigned long long relevant_from_pre(const CullPre &c, const Ball &ball, const DevLight &lt)
+{
+    bool rel;
+    if (!lt.spherical) {
+        const double along = c.wx * lt.sdir[0] + c.wy * lt.sdir[1] + c.wz * lt.sdir[2];
+        const double perp2 = c.ww - along * along * lt.inv_uu;
+        rel = !(perp2 > c.lim * c.lim) && !(along < -c.lim * lt.len_u);
+    } else {
+        const double ex = lt.p[0] - ball.cx, ey = lt.p[1] - ball.cy, ez = lt.p[2] - ball.cz;
+        const double ee = ex * ex + ey * ey + ez * ez;
+        const double e1 = fabs(ex) + fabs(ey) + fabs(ez);
+        const double we = c.wx * ex + c.wy * ey + c.wz * ez;
+        const double l2 = lt.p[0] * lt.p[0] + lt.p[1] * lt.p[1] + lt.p[2] * lt.p[2];
+        const double lim = c.lim + 1e-6 * e1 + 1e-12 * l2 * c.inv_r;
+        const double lim2 = lim * lim;
+        if (!(we > 0.0)) rel = !(c.ww > lim2);
+        else if (!(we < ee)) rel = !((c.ww - 2.0 * we) + ee > lim2);
+        else rel = !(c.ww * ee - we * we > lim2 * ee);
+    }
+    return __ballot(c.in_range && (c.always || rel));
+}
+
 __device__ __forceinline__ void blend(F3 &res, float ratio, const F3 &c)
 {
     // UPDATE_COLOR, src/update-cpu.cpp:100
@@ -439,7 +527,7 @@ struct LdsLayout {
         color = off; off = align16(off + 3 * WG * 4);
         shadow = off; off = align16(off + WG * shadow_words * 4);
         ball = off; off = align16(off + 4 * (uint32_t) sizeof(Ball));
-        misc = off; off = align16(off + 16);
+        misc = off; off = align16(off + 32);
         total = off;
     }
 };
@@ -448,10 +536,10 @@ constexpr int NO_BLOCKER = 0x7fffffff;
 
 // Phase B for one (chunk, light) item: is the lane's shadow ray blocked, and (COUNT builds) by which lowest
 // object index.  `blocker` keeps the lowest blocking index seen; without COUNT any blocker ends the search.
-template <bool COUNT, bool HAS_CUBIC>
+template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC>
 __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj,
-                                              const Mono &sm, double max_t, bool valid, const Ball &ball, const DevLight &lt,
-                                              uint32_t lane, Cnt<COUNT> &cnt)
+                                              const Mono &sm, double max_t, bool valid, const Ball &ball, const CullPre &pre,
+                                              const DevLight &lt, uint32_t lane, Cnt<COUNT> &cnt)
 {
     int blocker = NO_BLOCKER;
     const bool quad = fabs(sm.u2) > EPS;
@@ -460,7 +548,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
         const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
         unsigned long long cand = 0;
         if (fa.cull) {
-            unsigned long long it = relevant_mask(S.us, base, end, ball, lt, lane);
+            unsigned long long it = (base == 0) ? relevant_from_pre(pre, ball, lt) : relevant_mask(S.us, base, end, ball, lt, lane);
             if (lane == 0) cnt.add(7, end - base);
             if (valid) cnt.add(6, (unsigned long long) __popcll(it));
             while (it) { // wave-uniform loop over the spheres that survived the culling
@@ -495,7 +583,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
             }
         }
     }
-    for (uint32_t base = 0; base < fa.n_gq; base += 64) {
+    for (uint32_t base = 0; HAS_GQ && base < fa.n_gq; base += 64) {
         const uint32_t end = (base + 64 < fa.n_gq) ? base + 64 : fa.n_gq;
         unsigned long long cand = 0;
         if (valid) cnt.add(6, end - base);
@@ -542,12 +630,18 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
     return blocker;
 }
 
-template <bool COUNT, bool RGBA8, bool HAS_CUBIC>
-__global__ __launch_bounds__(256, RT_WF_OCC) void wavefront_tile_kernel(const FrameArgs fa, const unsigned char *__restrict__ gscene,
+// counters[] words used by the persistent-workgroup scheduler (the host zeroes the block once at rt_create; the
+// kernel leaves both words zero again, so back-to-back launches and graph replays need no memset)
+constexpr int CTR_TILE = 28; // next tile to hand out
+constexpr int CTR_DONE = 29; // workgroups that have left the tile loop
+
+template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC>
+__global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_tile_kernel(const FrameArgs fa, const unsigned char *__restrict__ gscene,
                                                               const DevLight *__restrict__ glight, void *__restrict__ fb,
                                                               unsigned long long *__restrict__ counters)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool NEED_CROSS = HAS_GQ || HAS_CUBIC;
     const LdsLayout L(fa.scene_bytes, fa.n_lights, fa.n_tab);
     const DevObject *gobj = reinterpret_cast<const DevObject *>(gscene);
     SceneLds S;
@@ -567,11 +661,19 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wavefront_tile_kernel(const Fr
     uint32_t *sshadow = reinterpret_cast<uint32_t *>(smem + L.shadow); // [WG][shadow_words] bit l: light l is blocked
     Ball *sball = reinterpret_cast<Ball *>(smem + L.ball);
     uint32_t *s_nhits = reinterpret_cast<uint32_t *>(smem + L.misc);
+    uint32_t *s_tile = s_nhits + 1;
+    uint32_t *s_live = s_nhits + 4; // [4] per-wave "still bouncing" flags
 
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const bool need_cross = (fa.n_gq != 0) || (HAS_CUBIC && fa.n_cub != 0);
     RT_STAMP_DECL
-    { // stage the scene blob (objects + class tables) and the lights into LDS once per workgroup, 16 B per lane per step
+    // The workgroup is PERSISTENT: it stages the scene once and then pulls 16x16 tiles from a global counter until
+    // none are left (heavy tiles cost ~20x an empty one, so the hand-out is dynamic; workgroups never wait for each
+    // other, so any grid size is safe).  Lane 0 asks for the next tile while the current one is being rendered.
+    unsigned long long next_tile = 0;
+#if RT_WF_PERSISTENT
+    if (tid == 0) next_tile = atomicAdd(&counters[CTR_TILE], 1ull);
+#endif
+    { // stage the scene blob (objects + class tables) and the lights into LDS, 16 B per lane per step
         const uint4 *src = reinterpret_cast<const uint4 *>(gscene);
         uint4 *dst = reinterpret_cast<uint4 *>(smem + L.scene);
         const uint32_t n16 = fa.scene_bytes / 16;
@@ -582,10 +684,10 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wavefront_tile_kernel(const Fr
         for (uint32_t i = tid; i < l16; i += WG) ldst[i] = lsrc[i];
         if (tid == 0) *s_nhits = 0;
     }
-    __syncthreads();
+    lds_barrier();
     { // t0 of every table entry for the primary-ray origin (src/update-cpu.cpp:123): the same for all pixels
         Mono mo;
-        mono_set_o(mo, D3{fa.origin[0], fa.origin[1], fa.origin[2]}, true);
+        mono_set_o<true>(mo, D3{fa.origin[0], fa.origin[1], fa.origin[2]});
         for (uint32_t j = tid; j < fa.n_tab; j += WG) {
             double t0;
             if (j < fa.n_us) t0 = us_t0(S.us[j], mo);
@@ -594,207 +696,245 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wavefront_tile_kernel(const Fr
             t0p[j] = t0;
         }
     }
-    __syncthreads();
     RT_STAMP(0);
-
-    // pixel of this lane: tile row-major, 16 pixels per row -> a wave covers a 16 x 4 block of the tile
-    const uint32_t tile_x = blockIdx.x % fa.tiles_x, tile_y = blockIdx.x / fa.tiles_x;
-    const uint32_t x = tile_x * RT_TILE + (tid & 15), lr = tile_y * RT_TILE + (tid >> 4);
-    const bool inside = x < fa.width && lr < fa.local_rows;
-    // lanes outside the image trace a clamped pixel (keeps the wave's primary cone tight); their result is dropped
-    const uint32_t xc = x < fa.width ? x : fa.width - 1, lrc = lr < fa.local_rows ? lr : fa.local_rows - 1;
-    const uint32_t y = global_row(fa, lrc);
 
     Cnt<COUNT> cnt;
     const F3 bg{fa.bg[0], fa.bg[1], fa.bg[2]};
-    F3 res = bg;
-    D3 o{fa.origin[0], fa.origin[1], fa.origin[2]};
-    D3 dir = primary_dir(fa, (int) xc, (int) y);
-    bool live = inside; // this pixel still has a ray to trace
-    bool first = true;
-    float cur_ratio = 1.0f;
-    uint32_t n_refl = 0;
-    if (inside) cnt.add(0);
+    for (;;) { // ======================= tile loop =======================
+#if RT_WF_PERSISTENT
+        if (tid == 0) {
+            *s_tile = (uint32_t) (next_tile < fa.n_tiles ? next_tile : fa.n_tiles);
+            if (next_tile < fa.n_tiles) next_tile = atomicAdd(&counters[CTR_TILE], 1ull); // prefetch: used next iteration
+        }
+        lds_barrier(); // also publishes t0p (first iteration) and separates tiles
+        const uint32_t tile = *s_tile;
+        if (tile >= fa.n_tiles) break;
+#else
+        lds_barrier();
+        const uint32_t tile = blockIdx.x;
+#endif
 
-    RT_STAMP(1);
-    for (;;) {
-        // ---------------- phase A: nearest hit, compaction ----------------
-        double best_t;
-        int best;
-        {
-            Mono m;
-            mono_set_o(m, o, need_cross);
-            mono_set_d(m, dir, need_cross);
-            mono_set_od(m, need_cross);
-            if (first) nearest<COUNT, HAS_CUBIC, true>(fa, S, gobj, m, live, lane, best_t, best, cnt);
-            else nearest<COUNT, HAS_CUBIC, false>(fa, S, gobj, m, live, lane, best_t, best, cnt);
-        }
-        RT_STAMP(2);
-        if (live) cnt.add(3, fa.n_obj);
-        const bool hit = live && best >= 0;
-        D3 sp{0.0, 0.0, 0.0}, sn{0.0, 0.0, 1.0};
-        if (hit) {
-            sp = D3{o.x + best_t * dir.x, o.y + best_t * dir.y, o.z + best_t * dir.z};
-            sn = normal_vector(S.obj[best].c, sp);
-            cnt.add(4);
-        }
-        if (live && !hit) { // the ray leaves the scene (src/update-cpu.cpp:93-95,112-115)
-            if (!first) blend(res, cur_ratio, bg);
-            live = false;
-        }
-        {
-            const unsigned long long hm = __ballot(hit);
-            uint32_t slot0 = 0;
-            if (lane == 0 && hm) slot0 = atomicAdd(s_nhits, (uint32_t) __popcll(hm));
-            slot0 = __shfl(slot0, 0);
-            if (hit) {
-                const uint32_t h = slot0 + (uint32_t) __popcll(hm & ((1ull << lane) - 1ull));
-                hp[h] = sp.x; hp[WG + h] = sp.y; hp[2 * WG + h] = sp.z;
-                hn[h] = sn.x; hn[WG + h] = sn.y; hn[2 * WG + h] = sn.z;
-                hidx[h] = (uint32_t) best;
-                hpix[h] = tid;
+        // pixel of this lane: tile row-major, 16 pixels per row -> a wave covers a 16 x 4 block of the tile
+        const uint32_t tile_x = tile % fa.tiles_x, tile_y = tile / fa.tiles_x;
+        const uint32_t x = tile_x * RT_TILE + (tid & 15), lr = tile_y * RT_TILE + (tid >> 4);
+        const bool inside = x < fa.width && lr < fa.local_rows;
+        // lanes outside the image trace a clamped pixel (keeps the wave's primary cone tight); their result is dropped
+        const uint32_t xc = x < fa.width ? x : fa.width - 1, lrc = lr < fa.local_rows ? lr : fa.local_rows - 1;
+        const uint32_t y = global_row(fa, lrc);
+
+        F3 res = bg;
+        D3 o{fa.origin[0], fa.origin[1], fa.origin[2]};
+        D3 dir = primary_dir(fa, (int) xc, (int) y);
+        bool live = inside; // this pixel still has a ray to trace
+        bool first = true;
+        float cur_ratio = 1.0f;
+        uint32_t n_refl = 0;
+        if (inside) cnt.add(0);
+
+        RT_STAMP(1);
+        for (;;) { // ----------------------- rounds -----------------------
+            // ---------------- phase A: nearest hit, compaction ----------------
+            double best_t;
+            int best;
+            {
+                Mono m;
+                mono_set_o<NEED_CROSS>(m, o);
+                mono_set_d<NEED_CROSS>(m, dir);
+                mono_set_od<NEED_CROSS>(m);
+                if (first) nearest<COUNT, HAS_GQ, HAS_CUBIC, true>(fa, S, gobj, m, live, lane, best_t, best, cnt);
+                else nearest<COUNT, HAS_GQ, HAS_CUBIC, false>(fa, S, gobj, m, live, lane, best_t, best, cnt);
             }
-        }
-        RT_STAMP(3);
-        __syncthreads();
-        RT_STAMP(4);
-        const uint32_t n_hits = *s_nhits;
-        const uint32_t n_chunks = (n_hits + 63) >> 6;
-
-        // ---------------- phase A': chunk bounding balls, clear shadow bits ----------------
-        if (tid < n_hits)
-            for (uint32_t w = 0; w < L.shadow_words; w++) sshadow[tid * L.shadow_words + w] = 0;
-        if (wave < n_chunks) { // wave-uniform
-            const bool v = tid < n_hits;
-            const double px = v ? hp[tid] : 0.0, py = v ? hp[WG + tid] : 0.0, pz = v ? hp[2 * WG + tid] : 0.0;
-            const double lox = wave_min(v ? px : INFINITY), hix = wave_max(v ? px : -INFINITY);
-            const double loy = wave_min(v ? py : INFINITY), hiy = wave_max(v ? py : -INFINITY);
-            const double loz = wave_min(v ? pz : INFINITY), hiz = wave_max(v ? pz : -INFINITY);
-            if (lane == 0) {
-                const double dx = hix - lox, dy = hiy - loy, dz = hiz - loz;
-                Ball b;
-                b.cx = 0.5 * (lox + hix);
-                b.cy = 0.5 * (loy + hiy);
-                b.cz = 0.5 * (loz + hiz);
-                // half diagonal of the box (rounded up) + the 1e-2 shadow bias of the ray origins
-                b.R = 0.5 * sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-9) + 1.01e-2;
-                sball[wave] = b;
-            }
-        }
-        __syncthreads();
-        RT_STAMP(5);
-
-        // ---------------- phase B: shadow rays ----------------
-        // Every wave visits every chunk and takes the lights l == (wave - chunk) mod 4 of it, so the per-chunk
-        // part of the ray (origin, its monomials) is formed once per wave and the lights of a tile with few hits
-        // are still spread over all four waves.
-        for (uint32_t c = 0; c < n_chunks; c++) { // wave-uniform
-            const uint32_t h = c * 64 + lane;
-            const bool valid = h < n_hits;
-            const uint32_t hs = valid ? h : c * 64;
-            const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]};
-            const D3 n{hn[hs], hn[WG + hs], hn[2 * WG + hs]};
-            Mono sm;
-            mono_set_o(sm, D3{p.x + SHADOW_BIAS * n.x, p.y + SHADOW_BIAS * n.y, p.z + SHADOW_BIAS * n.z}, need_cross);
-            const Ball ball = sball[c];
-            for (uint32_t l = (wave + 4u - (c & 3u)) & 3u; l < fa.n_lights; l += 4) {
-                const DevLight &lt = S.light[l]; // wave-uniform LDS reads
-                double max_t;
-                if (lt.spherical) {
-                    // shadow_ray, include/light_impl.h:19-21: (light - point) through FP32
-                    max_t = 1.0;
-                    const D3 sd{(double) (float) (lt.p[0] - p.x), (double) (float) (lt.p[1] - p.y), (double) (float) (lt.p[2] - p.z)};
-                    mono_set_d(sm, sd, need_cross);
-                } else {
-                    // include/light_impl.h:23-25: the per-light constant direction and its monomials
-                    max_t = 1e6;
-                    sm.d = D3{lt.sdir[0], lt.sdir[1], lt.sdir[2]};
-                    sm.dxx = lt.dxx; sm.dyy = lt.dyy; sm.dzz = lt.dzz;
-                    sm.dxy = lt.dxy; sm.dxz = lt.dxz; sm.dyz = lt.dyz;
-                    sm.u2 = lt.u2;
-                }
-                mono_set_od(sm, need_cross);
-                if (valid) cnt.add(1);
-                const int blocker = shadow_blocker<COUNT, HAS_CUBIC>(fa, S, gobj, sm, max_t, valid, ball, lt, lane, cnt);
-                if (valid) {
-                    // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
-                    cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
-                    if (blocker != NO_BLOCKER) atomicOr(&sshadow[h * L.shadow_words + (l >> 5)], 1u << (l & 31));
-                }
-            }
-        }
-        RT_STAMP(6);
-        __syncthreads();
-        RT_STAMP(7);
-
-        // ---------------- phase C: shade each hit, lights in order ----------------
-        if (tid < n_hits) {
-            const uint32_t h = tid;
-            const D3 p{hp[h], hp[WG + h], hp[2 * WG + h]};
-            const D3 n{hn[h], hn[WG + h], hn[2 * WG + h]};
-            const DevObject *ob = &S.obj[hidx[h]];
-            const F3 albedo{ob->albedo[0], ob->albedo[1], ob->albedo[2]};
-            F3 acc{0.0f, 0.0f, 0.0f};
-            for (uint32_t l = 0; l < fa.n_lights; l++) {
-                const bool blocked = (sshadow[h * L.shadow_words + (l >> 5)] >> (l & 31)) & 1u;
-                if (!blocked) {
-                    const DevLight &lt = S.light[l];
-                    F3 col = surface_color(lt.p, lt.color, lt.spherical != 0, p, n, albedo);
-                    acc.x += col.x;
-                    acc.y += col.y;
-                    acc.z += col.z;
-                }
-            }
-            const uint32_t px = hpix[h];
-            scolor[px] = (acc.x < 1.0f) ? acc.x : 1.0f; // glm::min(vec3(1.0f), acc)
-            scolor[WG + px] = (acc.y < 1.0f) ? acc.y : 1.0f;
-            scolor[2 * WG + px] = (acc.z < 1.0f) ? acc.z : 1.0f;
-        }
-        RT_STAMP(8);
-        __syncthreads();
-        if (tid == 0) *s_nhits = 0;
-
-        // ---------------- phase D: blend, set up the bounce ----------------
-        if (hit) {
-            const F3 oc{scolor[tid], scolor[WG + tid], scolor[2 * WG + tid]};
-            if (first) res = oc;
-            else blend(res, cur_ratio, oc);
-            const float refl = S.obj[best].refl;
-            if (!((double) refl > EPS)) {
+            RT_STAMP(2);
+            if (live) cnt.add(3, fa.n_obj);
+            const bool hit = live && best >= 0;
+            uint32_t my_slot = 0;
+            if (live && !hit) { // the ray leaves the scene (src/update-cpu.cpp:93-95,112-115)
+                if (!first) blend(res, cur_ratio, bg);
                 live = false;
-            } else {
-                cur_ratio *= refl;
-                if (n_refl == fa.max_refl) {
-                    blend(res, cur_ratio, bg);
+            }
+            {
+                const unsigned long long hm = __ballot(hit);
+                uint32_t slot0 = 0;
+                if (lane == 0 && hm) slot0 = atomicAdd(s_nhits, (uint32_t) __popcll(hm));
+                slot0 = __builtin_amdgcn_readfirstlane(slot0);
+                if (hit) {
+                    const D3 sp{o.x + best_t * dir.x, o.y + best_t * dir.y, o.z + best_t * dir.z};
+                    const D3 sn = normal_vector(S.obj[best].c, sp);
+                    cnt.add(4);
+                    my_slot = slot0 + (uint32_t) __popcll(hm & ((1ull << lane) - 1ull));
+                    hp[my_slot] = sp.x; hp[WG + my_slot] = sp.y; hp[2 * WG + my_slot] = sp.z;
+                    hn[my_slot] = sn.x; hn[WG + my_slot] = sn.y; hn[2 * WG + my_slot] = sn.z;
+                    hidx[my_slot] = (uint32_t) best;
+                    hpix[my_slot] = tid;
+                }
+            }
+            RT_STAMP(3);
+            lds_barrier();
+            RT_STAMP(4);
+            const uint32_t n_hits = *s_nhits;
+            const uint32_t n_chunks = (n_hits + 63) >> 6;
+
+            // ---------------- phase A': chunk bounding balls, clear shadow bits ----------------
+            if (tid < n_hits)
+                for (uint32_t w = 0; w < L.shadow_words; w++) sshadow[tid * L.shadow_words + w] = 0;
+            if (wave < n_chunks) { // wave-uniform
+                const bool v = tid < n_hits;
+                const double px = v ? hp[tid] : 0.0, py = v ? hp[WG + tid] : 0.0, pz = v ? hp[2 * WG + tid] : 0.0;
+                const double lox = wave_min(v ? px : INFINITY), hix = wave_max(v ? px : -INFINITY);
+                const double loy = wave_min(v ? py : INFINITY), hiy = wave_max(v ? py : -INFINITY);
+                const double loz = wave_min(v ? pz : INFINITY), hiz = wave_max(v ? pz : -INFINITY);
+                if (lane == 0) {
+                    const double dx = hix - lox, dy = hiy - loy, dz = hiz - loz;
+                    Ball b;
+                    b.cx = 0.5 * (lox + hix);
+                    b.cy = 0.5 * (loy + hiy);
+                    b.cz = 0.5 * (loz + hiz);
+                    // half diagonal of the box (rounded up) + the 1e-2 shadow bias of the ray origins
+                    b.R = 0.5 * sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-9) + 1.01e-2;
+                    sball[wave] = b;
+                }
+            }
+            lds_barrier();
+            RT_STAMP(5);
+
+            // ---------------- phase B: shadow rays ----------------
+            // Every wave visits every chunk and takes the lights l == (wave - chunk) mod 4 of it, so the per-chunk
+            // part of the ray (origin, its monomials) is formed once per wave and the lights of a tile with few
+            // hits are still spread over all four waves.
+            for (uint32_t c = 0; c < n_chunks; c++) { // wave-uniform
+                const uint32_t h = c * 64 + lane;
+                const bool valid = h < n_hits;
+                const uint32_t hs = valid ? h : c * 64;
+                const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]};
+                Mono sm;
+                {
+                    const D3 n{hn[hs], hn[WG + hs], hn[2 * WG + hs]};
+                    mono_set_o<NEED_CROSS>(sm, D3{p.x + SHADOW_BIAS * n.x, p.y + SHADOW_BIAS * n.y, p.z + SHADOW_BIAS * n.z});
+                }
+                const Ball ball = sball[c];
+                CullPre pre{};
+                if (fa.cull) pre = cull_prepare(S.us, fa.n_us, ball, lane);
+                for (uint32_t l = (wave + 4u - (c & 3u)) & 3u; l < fa.n_lights; l += 4) {
+                    const DevLight &lt = S.light[l]; // wave-uniform LDS reads
+                    double max_t;
+                    if (lt.spherical) {
+                        // shadow_ray, include/light_impl.h:19-21: (light - point) through FP32
+                        max_t = 1.0;
+                        const D3 sd{(double) (float) (lt.p[0] - p.x), (double) (float) (lt.p[1] - p.y), (double) (float) (lt.p[2] - p.z)};
+                        mono_set_d<NEED_CROSS>(sm, sd);
+                    } else {
+                        // include/light_impl.h:23-25: the per-light constant direction and its monomials
+                        max_t = 1e6;
+                        sm.d = D3{lt.sdir[0], lt.sdir[1], lt.sdir[2]};
+                        sm.dxx = lt.dxx; sm.dyy = lt.dyy; sm.dzz = lt.dzz;
+                        if (NEED_CROSS) { sm.dxy = lt.dxy; sm.dxz = lt.dxz; sm.dyz = lt.dyz; }
+                        sm.u2 = lt.u2;
+                    }
+                    mono_set_od<NEED_CROSS>(sm);
+                    if (valid) cnt.add(1);
+                    const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC>(fa, S, gobj, sm, max_t, valid, ball, pre, lt, lane, cnt);
+                    if (valid) {
+                        // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
+                        cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
+                        if (blocker != NO_BLOCKER) atomicOr(&sshadow[h * L.shadow_words + (l >> 5)], 1u << (l & 31));
+                    }
+                }
+            }
+            RT_STAMP(6);
+            lds_barrier();
+            RT_STAMP(7);
+
+            // ---------------- phase C: shade each hit, lights in order ----------------
+            if (tid < n_hits) {
+                const uint32_t h = tid;
+                const D3 p{hp[h], hp[WG + h], hp[2 * WG + h]};
+                const D3 n{hn[h], hn[WG + h], hn[2 * WG + h]};
+                const DevObject *ob = &S.obj[hidx[h]];
+                const F3 albedo{ob->albedo[0], ob->albedo[1], ob->albedo[2]};
+                F3 acc{0.0f, 0.0f, 0.0f};
+                for (uint32_t l = 0; l < fa.n_lights; l++) {
+                    const bool blocked = (sshadow[h * L.shadow_words + (l >> 5)] >> (l & 31)) & 1u;
+                    if (!blocked) {
+                        const DevLight &lt = S.light[l];
+                        F3 col = surface_color(lt.p, lt.color, lt.spherical != 0, p, n, albedo);
+                        acc.x += col.x;
+                        acc.y += col.y;
+                        acc.z += col.z;
+                    }
+                }
+                const uint32_t px = hpix[h];
+                scolor[px] = (acc.x < 1.0f) ? acc.x : 1.0f; // glm::min(vec3(1.0f), acc)
+                scolor[WG + px] = (acc.y < 1.0f) ? acc.y : 1.0f;
+                scolor[2 * WG + px] = (acc.z < 1.0f) ? acc.z : 1.0f;
+            }
+            RT_STAMP(8);
+            lds_barrier();
+            if (tid == 0) *s_nhits = 0;
+
+            // ---------------- phase D: blend, set up the bounce ----------------
+            if (hit) {
+                const F3 oc{scolor[tid], scolor[WG + tid], scolor[2 * WG + tid]};
+                if (first) res = oc;
+                else blend(res, cur_ratio, oc);
+                const float refl = S.obj[best].refl;
+                if (!((double) refl > EPS)) {
                     live = false;
                 } else {
-                    n_refl++;
-                    dir = reflect_ray(dir, sn);
-                    cnt.add(2);
-                    o = D3{sp.x + SHADOW_BIAS * sn.x, sp.y + SHADOW_BIAS * sn.y, sp.z + SHADOW_BIAS * sn.z};
+                    cur_ratio *= refl;
+                    if (n_refl == fa.max_refl) {
+                        blend(res, cur_ratio, bg);
+                        live = false;
+                    } else {
+                        n_refl++;
+                        // hit point and normal come back from this lane's queue slot (kept out of registers across B / C)
+                        const D3 sp{hp[my_slot], hp[WG + my_slot], hp[2 * WG + my_slot]};
+                        const D3 sn{hn[my_slot], hn[WG + my_slot], hn[2 * WG + my_slot]};
+                        dir = reflect_ray(dir, sn);
+                        cnt.add(2);
+                        o = D3{sp.x + SHADOW_BIAS * sn.x, sp.y + SHADOW_BIAS * sn.y, sp.z + SHADOW_BIAS * sn.z};
+                    }
                 }
             }
+            first = false; // wave-uniform: round 0 is over for everybody
+            // any pixel of the tile still bouncing?  one flag per wave, one barrier (which also orders the s_nhits
+            // reset and the queue reads before the next round)
+            const unsigned long long live_mask = __ballot(live); // all lanes vote, then lane 0 publishes
+            if (lane == 0) s_live[wave] = live_mask != 0ull ? 1u : 0u;
+            lds_barrier();
+            const uint32_t more = s_live[0] | s_live[1] | s_live[2] | s_live[3];
+            RT_STAMP(9);
+            if (!more) break;
         }
-        first = false; // wave-uniform: round 0 is over for everybody
-        const int more = __syncthreads_or(live ? 1 : 0); // also orders the s_nhits reset before the next round
-        RT_STAMP(9);
-        if (!more) break;
+
+        if (inside) {
+            const size_t pix = (size_t) lr * fa.width + x;
+            if (fa.rgba8) {
+                uchar4 px;
+                px.x = (unsigned char) (int) (res.x * 255.0f + 0.5f);
+                px.y = (unsigned char) (int) (res.y * 255.0f + 0.5f);
+                px.z = (unsigned char) (int) (res.z * 255.0f + 0.5f);
+                px.w = 255;
+                reinterpret_cast<uchar4 *>(fb)[pix] = px;
+            } else {
+                reinterpret_cast<float4 *>(fb)[pix] = make_float4(res.x, res.y, res.z, 1.0f);
+            }
+        }
+        RT_STAMP(10);
+#if !RT_WF_PERSISTENT
+        break;
+#endif
     }
 
-    if (inside) {
-        const size_t pix = (size_t) lr * fa.width + x;
-        if (RGBA8) {
-            uchar4 px;
-            px.x = (unsigned char) (int) (res.x * 255.0f + 0.5f);
-            px.y = (unsigned char) (int) (res.y * 255.0f + 0.5f);
-            px.z = (unsigned char) (int) (res.z * 255.0f + 0.5f);
-            px.w = 255;
-            reinterpret_cast<uchar4 *>(fb)[pix] = px;
-        } else {
-            reinterpret_cast<float4 *>(fb)[pix] = make_float4(res.x, res.y, res.z, 1.0f);
+#if RT_WF_PERSISTENT
+    // scheduler hygiene: the last workgroup out zeroes both words for the next launch / graph replay
+    if (tid == 0) {
+        const unsigned long long done = atomicAdd(&counters[CTR_DONE], 1ull);
+        if (done == (unsigned long long) gridDim.x - 1ull) {
+            atomicExch(&counters[CTR_TILE], 0ull);
+            atomicExch(&counters[CTR_DONE], 0ull);
         }
     }
-    RT_STAMP(10);
+#endif
     RT_STAMP_FLUSH(counters, lane);
     cnt.flush(counters);
 }
@@ -806,18 +946,23 @@ extern "C" size_t RT_SYM(rt_wavefront_lds_bytes)(uint32_t scene_bytes, uint32_t 
     return RT_SYM(rtw)::LdsLayout(scene_bytes, n_lights, n_tab).total;
 }
 
+// `grid_cap`: number of workgroups the device can keep resident (CUs x workgroups per CU), computed once by rt_create.
 extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const DevObject *gobj, const DevLight *glight,
-                                                   void *fb, unsigned long long *counters, int rgba8, int count,
+                                                   void *fb, unsigned long long *counters, int count, uint32_t grid_cap,
                                                    hipStream_t stream)
 {
     using namespace RT_SYM(rtw);
-    const uint32_t tiles_y = (fa->local_rows + RT_TILE - 1) / RT_TILE;
-    const dim3 grid(fa->tiles_x * tiles_y), block(WG);
-    if (grid.x == 0) return hipSuccess;
+    if (fa->n_tiles == 0) return hipSuccess;
+#if RT_WF_PERSISTENT
+    const dim3 grid(fa->n_tiles < grid_cap ? fa->n_tiles : grid_cap), block(WG);
+#else
+    (void) grid_cap;
+    const dim3 grid(fa->n_tiles), block(WG);
+#endif
     const size_t lds = LdsLayout(fa->scene_bytes, fa->n_lights, fa->n_tab).total;
     const unsigned char *gs = reinterpret_cast<const unsigned char *>(gobj);
-    const int sel = (count ? 4 : 0) | (rgba8 ? 2 : 0) | (fa->n_cub ? 1 : 0);
-#define RT_LAUNCH(C, R, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, R, Q>), grid, block, lds, stream, *fa, gs, glight, fb, counters)
+    const int sel = (count ? 4 : 0) | (fa->n_gq ? 2 : 0) | (fa->n_cub ? 1 : 0);
+#define RT_LAUNCH(C, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q>), grid, block, lds, stream, *fa, gs, glight, fb, counters)
     switch (sel) {
     case 0: RT_LAUNCH(false, false, false); break;
     case 1: RT_LAUNCH(false, false, true); break;
@@ -830,4 +975,15 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
     }
 #undef RT_LAUNCH
     return hipGetLastError();
+}
+
+// workgroups of this kernel that fit on one CU (for sizing the persistent grid)
+extern "C" hipError_t RT_SYM(rt_wavefront_blocks_per_cu)(uint32_t scene_bytes, uint32_t n_lights, uint32_t n_tab, int has_gq,
+                                                          int has_cubic, int *out)
+{
+    using namespace RT_SYM(rtw);
+    const size_t lds = LdsLayout(scene_bytes, n_lights, n_tab).total;
+    const void *fn = has_cubic ? (has_gq ? (const void *) wavefront_tile_kernel<false, true, true> : (const void *) wavefront_tile_kernel<false, false, true>)
+                               : (has_gq ? (const void *) wavefront_tile_kernel<false, true, false> : (const void *) wavefront_tile_kernel<false, false, false>);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, (int) WG, lds);
 }

@@ -21,10 +21,10 @@
 // kernels, one set per floating-point contraction mode (rt_kernels.hip)
 extern "C" hipError_t rt_launch_trace_strict(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, int, hipStream_t);
 extern "C" hipError_t rt_launch_trace_fast(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, int, hipStream_t);
-extern "C" hipError_t rt_launch_wavefront_strict(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, uint32_t, hipStream_t);
-extern "C" hipError_t rt_launch_wavefront_fast(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, uint32_t, hipStream_t);
-extern "C" hipError_t rt_wavefront_blocks_per_cu_strict(uint32_t, uint32_t, uint32_t, int, int, int *);
-extern "C" size_t rt_wavefront_lds_bytes_strict(uint32_t, uint32_t, uint32_t);
+extern "C" hipError_t rt_launch_wavefront_strict(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, const double *, const double *, hipStream_t);
+extern "C" hipError_t rt_launch_wavefront_fast(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, const double *, const double *, hipStream_t);
+
+extern "C" size_t rt_wavefront_lds_bytes_strict(uint32_t, uint32_t);
 extern "C" hipError_t rt_launch_assemble_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 
 namespace {
@@ -99,7 +99,7 @@ struct rt_ctx {
     bool counted = false;
     bool zero_counters = false; // diagnostic builds: clear counters[] before every render
     uint64_t *d_stamps = nullptr;
-    uint32_t grid_cap = 0; // workgroups the device keeps resident: persistent grid size
+    double *d_camx = nullptr, *d_camy = nullptr; // per-column / per-row camera-plane coordinates
     size_t n_stamp_rows = 0;
 };
 
@@ -397,7 +397,6 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
     fa.n_gq = (uint32_t) t_gq.size();
     fa.n_lin = (uint32_t) t_lin.size();
     fa.n_cub = (uint32_t) t_cub.size();
-    fa.n_tab = fa.n_us + fa.n_gq + fa.n_lin;
     size_t off = up16(sizeof(DevObject) * objs.size());
     fa.off_us = (uint32_t) off; off = up16(off + sizeof(UsEntry) * t_us.size());
     fa.off_gq = (uint32_t) off; off = up16(off + sizeof(GqEntry) * t_gq.size());
@@ -431,10 +430,10 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
         l.len_u = 1.001 * std::sqrt(l.u2);
     }
 
-    if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.scene_bytes, sd->n_lights, fa.n_tab) > 160u * 1024u) {
+    if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.scene_bytes, sd->n_lights) > 160u * 1024u) {
         delete ctx;
         return fail(RT_ERR_SCENE, "rt_create: scene needs %zu bytes of LDS per workgroup (limit 160 KiB)",
-                    rt_wavefront_lds_bytes_strict(fa.scene_bytes, sd->n_lights, fa.n_tab));
+                    rt_wavefront_lds_bytes_strict(fa.scene_bytes, sd->n_lights));
     }
     int rc = RT_OK;
     auto hip_ok = [&](hipError_t err, const char *what) {
@@ -457,18 +456,32 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
         return rc;
     }
     {
-        // persistent grid: CUs x workgroups per CU for the instantiation this scene uses
-        hipDeviceProp_t prop;
-        int per_cu = 0;
-        if (hipGetDeviceProperties(&prop, device) != hipSuccess) prop.multiProcessorCount = 256;
-        if (rt_wavefront_blocks_per_cu_strict(fa.scene_bytes, fa.n_lights, fa.n_tab, fa.n_gq != 0, fa.n_cub != 0, &per_cu) != hipSuccess || per_cu < 1)
-            per_cu = 2;
-        ctx->grid_cap = (uint32_t) prop.multiProcessorCount * (uint32_t) per_cu;
+        // camera-plane coordinates of every pixel column / row: render_pixel's camera_x / camera_y
+        // (src/update-cpu.cpp:84-87) depend only on the pixel index and the scene, so they are evaluated here once,
+        // with the same IEEE operations in the same order (this file is compiled with -ffp-contract=off)
+        std::vector<double> cx(sd->width), cy(sd->height);
+        for (uint32_t x = 0; x < sd->width; x++) {
+            const double ndc_x = ((int) x + 0.5) / (int) sd->width;
+            cx[x] = (2.0 * ndc_x - 1.0) * fa.aspect * fa.tan_half_fov;
+        }
+        for (uint32_t y = 0; y < sd->height; y++) {
+            const double ndc_y = ((int) y + 0.5) / (int) sd->height;
+            cy[y] = (2.0 * ndc_y - 1.0) * fa.tan_half_fov;
+        }
+        hip_ok(hipMalloc((void **) &ctx->d_camx, sizeof(double) * sd->width), "hipMalloc(camx)") &&
+            hip_ok(hipMalloc((void **) &ctx->d_camy, sizeof(double) * sd->height), "hipMalloc(camy)") &&
+            hip_ok(hipMemcpy(ctx->d_camx, cx.data(), sizeof(double) * sd->width, hipMemcpyHostToDevice), "hipMemcpy(camx)") &&
+            hip_ok(hipMemcpy(ctx->d_camy, cy.data(), sizeof(double) * sd->height, hipMemcpyHostToDevice), "hipMemcpy(camy)");
+        if (rc != RT_OK) {
+            std::string keep = g_last_error;
+            rt_destroy(ctx);
+            g_last_error = keep;
+            return rc;
+        }
     }
     ctx->zero_counters = std::getenv("MI355RT_DEBUG_COUNTERS") != nullptr;
     if (ctx->zero_counters) { // room for the stamp rows of a diagnostic (STAMPS=1) build: one per wave
-        // one row per wave of the largest grid either scheduling mode can launch
-        ctx->n_stamp_rows = (size_t) (fa.n_tiles > ctx->grid_cap ? fa.n_tiles : ctx->grid_cap) * 4;
+        ctx->n_stamp_rows = (size_t) fa.n_tiles * 4; // one row per wave
         if (hipMalloc((void **) &ctx->d_stamps, ctx->n_stamp_rows * 12 * sizeof(uint64_t) + 8) != hipSuccess) ctx->d_stamps = nullptr;
         else (void) hipMemset(ctx->d_stamps, 0, ctx->n_stamp_rows * 12 * sizeof(uint64_t));
     }
@@ -505,8 +518,8 @@ extern "C" int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *
         e = fast ? rt_launch_trace_fast(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream)
                  : rt_launch_trace_strict(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, rgba8, count, stream);
     else
-        e = fast ? rt_launch_wavefront_fast(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, count, ctx->grid_cap, stream)
-                 : rt_launch_wavefront_strict(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, count, ctx->grid_cap, stream);
+        e = fast ? rt_launch_wavefront_fast(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, count, ctx->d_camx, ctx->d_camy, stream)
+                 : rt_launch_wavefront_strict(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, count, ctx->d_camx, ctx->d_camy, stream);
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     ctx->counted = count != 0;
     if (ms) {
@@ -610,6 +623,8 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     if (ctx->d_fb) (void) hipFree(ctx->d_fb);
     if (ctx->d_counters) (void) hipFree(ctx->d_counters);
     if (ctx->d_stamps) (void) hipFree(ctx->d_stamps);
+    if (ctx->d_camx) (void) hipFree(ctx->d_camx);
+    if (ctx->d_camy) (void) hipFree(ctx->d_camy);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     delete ctx;

@@ -328,6 +328,28 @@ __device__ __forceinline__ F3 surface_color(const double *__restrict__ lp, const
     return F3{albedo.x / PI_F * col.x * mx, albedo.y / PI_F * col.y * mx, albedo.z / PI_F * col.z * mx};
 }
 
+// surface_color with the per-hit factor object_color / pi formed once by the caller: the reference evaluates
+// ((object_color / pi) * color) * max(0, n.l) left to right (include/light_impl.h:43), so hoisting the first
+// division out of the light loop does not change a bit -- it removes three FP32 divisions per (hit, light).
+__device__ __forceinline__ F3 surface_color_pre(const double *__restrict__ lp, const float *__restrict__ lc, bool spherical,
+                                                const D3 &p, const D3 &n, const F3 &albedo_over_pi)
+{
+    D3 dir;
+    F3 col;
+    if (spherical) {
+        dir = D3{lp[0] - p.x, lp[1] - p.y, lp[2] - p.z};
+        float denom = 4.0f * PI_F * (float) dot3(dir, dir);
+        col = F3{lc[0] / denom, lc[1] / denom, lc[2] / denom};
+        dir = normalize3(dir);
+    } else {
+        dir = D3{lp[0], lp[1], lp[2]};
+        col = F3{lc[0], lc[1], lc[2]};
+    }
+    float lam = (float) dot3(n, dir);
+    float mx = (0.0f < lam) ? lam : 0.0f;
+    return F3{albedo_over_pi.x * col.x * mx, albedo_over_pi.y * col.y * mx, albedo_over_pi.z * col.z * mx};
+}
+
 // reflect_ray, include/light_impl.h:46-49
 __device__ __forceinline__ D3 reflect_ray(const D3 &d, const D3 &n)
 {
@@ -344,6 +366,20 @@ __device__ __forceinline__ D3 primary_dir(const FrameArgs &fa, int x, int y)
     double cy = (2.0 * ndc_y - 1.0) * fa.tan_half_fov;
     const double *m = fa.cam;
     // dmat4 * dvec4(cx, cy, 1, 1): (m0*v.x + m1*v.y) + (m2*v.z + m3*v.w)
+    D3 w;
+    w.x = (m[0] * cx + m[4] * cy) + (m[8] * 1.0 + m[12] * 1.0);
+    w.y = (m[1] * cx + m[5] * cy) + (m[9] * 1.0 + m[13] * 1.0);
+    w.z = (m[2] * cx + m[6] * cy) + (m[10] * 1.0 + m[14] * 1.0);
+    D3 rel{w.x - fa.origin[0], w.y - fa.origin[1], w.z - fa.origin[2]};
+    return normalize3(rel);
+}
+
+// The same direction from per-column / per-row tables: camera_x and camera_y above depend only on the pixel
+// column / row and on (width, height, fov), so rt_create evaluates them once on the host with the same IEEE
+// operations (two FP64 divisions per pixel saved); the per-frame part is the camera matrix and the normalisation.
+__device__ __forceinline__ D3 primary_dir_tab(const FrameArgs &fa, double cx, double cy)
+{
+    const double *m = fa.cam;
     D3 w;
     w.x = (m[0] * cx + m[4] * cy) + (m[8] * 1.0 + m[12] * 1.0);
     w.y = (m[1] * cx + m[5] * cy) + (m[9] * 1.0 + m[13] * 1.0);

@@ -93,7 +93,6 @@ struct FrameArgs {
     uint32_t n_us, n_gq, n_lin, n_cub;
     uint32_t off_us, off_gq, off_lin, off_cub; // byte offsets into the blob
     uint32_t scene_bytes;                       // blob size, multiple of 16
-    uint32_t n_tab;                             // n_us + n_gq + n_lin: entries of the primary-ray t0 table
     uint32_t n_tiles;                           // tiles of this rank's rows (tiles_x * tiles_y)
     uint32_t rgba8;                             // 1: store iround(c*255) RGBA8 instead of RGBA32F
 };

@@ -68,9 +68,7 @@ constexpr uint32_t WG = 256; // threads per workgroup = pixels per tile
 #ifndef RT_WF_OCC
 #define RT_WF_OCC 3
 #endif
-#ifndef RT_WF_PERSISTENT
-#define RT_WF_PERSISTENT 0
-#endif
+
 
 // counters[]: 0 primary 1 shadow 2 reflect 3 tests (reference-equivalent, valid with cull = 0) 4 hits
 //             5 solves executed 6 tests executed 7 cull evaluations
@@ -98,6 +96,19 @@ __device__ __forceinline__ bool needs_solve(double t2, double t1, double t0)
         double delta = t1 * t1 - 4.0 * t2 * t0;
         return !(delta < 0);
     }
+    return fabs(t1) > EPS;
+}
+
+// Unit spheres (t2 = |d|^2 > 0): does the reference's solver produce a root that can pass a "t >= EPS" test?
+//   * discriminant < 0                      -> it returns -1                      (include/surface_impl.h:141-144)
+//   * t1 > 0 and t0 > 0 (origin outside, moving away) -> both roots are <= 0: with t2, t0 > 0 the computed
+//     discriminant is <= fl(t1*t1), a correctly rounded sqrt of that is <= t1, so (-t1 + sqrt)/(2 t2) <= 0 and
+//     (-t1 - sqrt)/(2 t2) < 0 in the reference's own floating-point evaluation, not just in exact arithmetic.
+// Either way neither the nearest-hit test (t >= EPS) nor the shadow test (t > EPS) can accept, so the sqrt and the
+// divisions need not be executed.  This removes the "own sphere" solve of every shadow ray that leaves a lit surface.
+__device__ __forceinline__ bool us_needs_solve(bool quad, double four_t2, double t1, double t0)
+{
+    if (quad) return !(t1 * t1 - four_t2 * t0 < 0) && !(t1 > 0.0 && t0 > 0.0);
     return fabs(t1) > EPS;
 }
 
@@ -203,7 +214,6 @@ struct SceneLds {
     const LinEntry *lin;
     const uint32_t *cub;
     const DevLight *light;
-    const double *t0p; // [n_us | n_gq | n_lin] t0 of each table entry for the frame's primary-ray origin
 };
 
 // Workgroup barrier for LDS-only communication: release/acquire at workgroup scope on the LDS address space only,
@@ -285,8 +295,9 @@ __device__ __forceinline__ unsigned long long primary_cone_mask(const UsEntry *u
     return __ballot(rel);
 }
 
-// Phase A.  PRIMARY: every lane's ray starts at the frame's origin -> t0 comes from the per-object table and
-// the unit spheres are first culled against the wave's ray cone.
+// Phase A.  PRIMARY: every lane's ray starts at the frame's origin, so the unit spheres are first culled against
+// the wave's ray cone.  `S` may point at the LDS copy of the scene or (round 0, before anything is staged) at the
+// blob in global memory: wave-uniform reads then become scalar loads, per-lane reads vector loads.
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool PRIMARY>
 __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj, const Mono &m,
                                         bool live, uint32_t lane, double &best_t, int &best, Cnt<COUNT> &cnt)
@@ -320,8 +331,8 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
                 it &= it - 1;
                 const UsEntry e = S.us[base + b];
                 const double t1 = us_t1(e, m);
-                const double t0 = S.t0p[base + b];
-                const bool need = quad ? !(t1 * t1 - four_t2 * t0 < 0) : (fabs(t1) > EPS);
+                const double t0 = us_t0(e, m);
+                const bool need = us_needs_solve(quad, four_t2, t1, t0);
                 cand |= need ? (1ull << b) : 0ull;
             }
         } else {
@@ -330,8 +341,8 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
             for (uint32_t j = base; j < end; j++) { // wave-uniform: LDS broadcast reads, no branches
                 const UsEntry e = S.us[j];
                 const double t1 = us_t1(e, m);
-                const double t0 = PRIMARY ? S.t0p[j] : us_t0(e, m);
-                const bool need = quad ? !(t1 * t1 - four_t2 * t0 < 0) : (fabs(t1) > EPS);
+                const double t0 = us_t0(e, m);
+                const bool need = us_needs_solve(quad, four_t2, t1, t0);
                 cand |= need ? (1ull << (j - base)) : 0ull;
             }
         }
@@ -341,7 +352,7 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
             cand &= cand - 1;
             const UsEntry e = S.us[base + b]; // LDS gather
             const double t1 = us_t1(e, m);
-            const double t0 = PRIMARY ? S.t0p[base + b] : us_t0(e, m);
+            const double t0 = us_t0(e, m);
             const double t = solve_quadlin(m.u2, t1, t0);
             cnt.add(5);
             accept(t, (int) e.orig, best_t, best);
@@ -354,7 +365,7 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
 #pragma unroll 2
         for (uint32_t j = base; j < end; j++) {
             const GqEntry e = S.gq[j];
-            const double t0 = PRIMARY ? S.t0p[fa.n_us + j] : gq_t0(e, m);
+            const double t0 = gq_t0(e, m);
             cand |= needs_solve(gq_t2(e, m), gq_t1(e, m), t0) ? (1ull << (j - base)) : 0ull;
         }
         if (!live) cand = 0;
@@ -362,7 +373,7 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
             const int b = __builtin_ctzll(cand);
             cand &= cand - 1;
             const GqEntry e = S.gq[base + b];
-            const double t0 = PRIMARY ? S.t0p[fa.n_us + base + b] : gq_t0(e, m);
+            const double t0 = gq_t0(e, m);
             const double t = solve_quadlin(gq_t2(e, m), gq_t1(e, m), t0);
             cnt.add(5);
             accept(t, (int) e.orig, best_t, best);
@@ -371,7 +382,7 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
     for (uint32_t j = 0; j < fa.n_lin; j++) { // planes: every lane needs the one division, nothing to defer
         const LinEntry e = S.lin[j];
         const double t1 = lin_t1(e, m);
-        const double t0 = PRIMARY ? S.t0p[fa.n_us + fa.n_gq + j] : lin_t0(e, m);
+        const double t0 = lin_t0(e, m);
         const double t = (fabs(t1) > EPS) ? -t0 / t1 : -1.0;
         if (live) {
             cnt.add(5);
@@ -511,15 +522,14 @@ __host__ __device__ inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15
 
 // LDS carve-up (dynamic shared memory), shared by kernel and launcher.
 struct LdsLayout {
-    uint32_t scene, light, t0p, hp, hn, hidx, hpix, color, shadow, ball, misc, total, shadow_words;
-    __host__ __device__ LdsLayout(uint32_t scene_bytes, uint32_t n_lights, uint32_t n_tab)
+    uint32_t scene, light, hp, hn, hidx, hpix, color, shadow, ball, misc, total, shadow_words;
+    __host__ __device__ LdsLayout(uint32_t scene_bytes, uint32_t n_lights)
     {
         shadow_words = (n_lights + 31) / 32;
         if (shadow_words == 0) shadow_words = 1;
         uint32_t off = 0;
         scene = off; off = align16(off + scene_bytes);
         light = off; off = align16(off + n_lights * (uint32_t) sizeof(DevLight));
-        t0p = off; off = align16(off + n_tab * 8);
         hp = off; off = align16(off + 3 * WG * 8);
         hn = off; off = align16(off + 3 * WG * 8);
         hidx = off; off = align16(off + WG * 4);
@@ -556,7 +566,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
                 it &= it - 1;
                 const UsEntry e = S.us[base + b];
                 const double t1 = us_t1(e, sm), t0 = us_t0(e, sm);
-                const bool need = quad ? !(t1 * t1 - four_t2 * t0 < 0) : (fabs(t1) > EPS);
+                const bool need = us_needs_solve(quad, four_t2, t1, t0);
                 cand |= need ? (1ull << b) : 0ull;
             }
         } else {
@@ -565,7 +575,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
             for (uint32_t j = base; j < end; j++) {
                 const UsEntry e = S.us[j];
                 const double t1 = us_t1(e, sm), t0 = us_t0(e, sm);
-                const bool need = quad ? !(t1 * t1 - four_t2 * t0 < 0) : (fabs(t1) > EPS);
+                const bool need = us_needs_solve(quad, four_t2, t1, t0);
                 cand |= need ? (1ull << (j - base)) : 0ull;
             }
         }
@@ -630,29 +640,30 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
     return blocker;
 }
 
-// counters[] words used by the persistent-workgroup scheduler (the host zeroes the block once at rt_create; the
-// kernel leaves both words zero again, so back-to-back launches and graph replays need no memset)
-constexpr int CTR_TILE = 28; // next tile to hand out
-constexpr int CTR_DONE = 29; // workgroups that have left the tile loop
-
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC>
 __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_tile_kernel(const FrameArgs fa, const unsigned char *__restrict__ gscene,
                                                               const DevLight *__restrict__ glight, void *__restrict__ fb,
-                                                              unsigned long long *__restrict__ counters)
+                                                              unsigned long long *__restrict__ counters,
+                                                              const double *__restrict__ camx, const double *__restrict__ camy)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool NEED_CROSS = HAS_GQ || HAS_CUBIC;
-    const LdsLayout L(fa.scene_bytes, fa.n_lights, fa.n_tab);
+    const LdsLayout L(fa.scene_bytes, fa.n_lights);
     const DevObject *gobj = reinterpret_cast<const DevObject *>(gscene);
-    SceneLds S;
+    SceneLds S; // the scene staged in LDS (only tiles with hits ever stage it)
     S.obj = reinterpret_cast<const DevObject *>(smem + L.scene);
     S.us = reinterpret_cast<const UsEntry *>(smem + L.scene + fa.off_us);
     S.gq = reinterpret_cast<const GqEntry *>(smem + L.scene + fa.off_gq);
     S.lin = reinterpret_cast<const LinEntry *>(smem + L.scene + fa.off_lin);
     S.cub = reinterpret_cast<const uint32_t *>(smem + L.scene + fa.off_cub);
     S.light = reinterpret_cast<const DevLight *>(smem + L.light);
-    double *t0p = reinterpret_cast<double *>(smem + L.t0p);
-    S.t0p = t0p;
+    SceneLds G; // the same tables where they live in global memory (round 0 runs straight from there)
+    G.obj = gobj;
+    G.us = reinterpret_cast<const UsEntry *>(gscene + fa.off_us);
+    G.gq = reinterpret_cast<const GqEntry *>(gscene + fa.off_gq);
+    G.lin = reinterpret_cast<const LinEntry *>(gscene + fa.off_lin);
+    G.cub = reinterpret_cast<const uint32_t *>(gscene + fa.off_cub);
+    G.light = glight;
     double *hp = reinterpret_cast<double *>(smem + L.hp);   // [3][WG] hit points (SoA: lane-consecutive, conflict-free)
     double *hn = reinterpret_cast<double *>(smem + L.hn);   // [3][WG] hit normals
     uint32_t *hidx = reinterpret_cast<uint32_t *>(smem + L.hidx); // object of hit h
@@ -660,59 +671,22 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
     float *scolor = reinterpret_cast<float *>(smem + L.color);    // [3][WG] direct lighting of the pixel's hit this round
     uint32_t *sshadow = reinterpret_cast<uint32_t *>(smem + L.shadow); // [WG][shadow_words] bit l: light l is blocked
     Ball *sball = reinterpret_cast<Ball *>(smem + L.ball);
-    uint32_t *s_nhits = reinterpret_cast<uint32_t *>(smem + L.misc);
-    uint32_t *s_tile = s_nhits + 1;
-    uint32_t *s_live = s_nhits + 4; // [4] per-wave "still bouncing" flags
+    uint32_t *s_wcount = reinterpret_cast<uint32_t *>(smem + L.misc); // [4] hits found by each wave this round
+    uint32_t *s_live = s_wcount + 4;                                  // [4] per-wave "still bouncing" flags
 
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     RT_STAMP_DECL
-    // The workgroup is PERSISTENT: it stages the scene once and then pulls 16x16 tiles from a global counter until
-    // none are left (heavy tiles cost ~20x an empty one, so the hand-out is dynamic; workgroups never wait for each
-    // other, so any grid size is safe).  Lane 0 asks for the next tile while the current one is being rendered.
-    unsigned long long next_tile = 0;
-#if RT_WF_PERSISTENT
-    if (tid == 0) next_tile = atomicAdd(&counters[CTR_TILE], 1ull);
-#endif
-    { // stage the scene blob (objects + class tables) and the lights into LDS, 16 B per lane per step
-        const uint4 *src = reinterpret_cast<const uint4 *>(gscene);
-        uint4 *dst = reinterpret_cast<uint4 *>(smem + L.scene);
-        const uint32_t n16 = fa.scene_bytes / 16;
-        for (uint32_t i = tid; i < n16; i += WG) dst[i] = src[i];
-        const uint4 *lsrc = reinterpret_cast<const uint4 *>(glight);
-        uint4 *ldst = reinterpret_cast<uint4 *>(smem + L.light);
-        const uint32_t l16 = fa.n_lights * (uint32_t) (sizeof(DevLight) / 16);
-        for (uint32_t i = tid; i < l16; i += WG) ldst[i] = lsrc[i];
-        if (tid == 0) *s_nhits = 0;
-    }
-    lds_barrier();
-    { // t0 of every table entry for the primary-ray origin (src/update-cpu.cpp:123): the same for all pixels
-        Mono mo;
-        mono_set_o<true>(mo, D3{fa.origin[0], fa.origin[1], fa.origin[2]});
-        for (uint32_t j = tid; j < fa.n_tab; j += WG) {
-            double t0;
-            if (j < fa.n_us) t0 = us_t0(S.us[j], mo);
-            else if (j < fa.n_us + fa.n_gq) t0 = gq_t0(S.gq[j - fa.n_us], mo);
-            else t0 = lin_t0(S.lin[j - fa.n_us - fa.n_gq], mo);
-            t0p[j] = t0;
-        }
-    }
+    // No prologue: 83 % of the tiles of a typical frame contain no hit at all, and for those the whole job is
+    // "primary rays miss, store the background".  Round 0 therefore reads the (culled, tiny) part of the tables it
+    // needs straight from global memory -- the blob is a few KB and lives in L2 / the scalar cache -- and the scene is
+    // only staged into LDS once the tile is known to have hits (`staged`).
+    bool staged = false;
     RT_STAMP(0);
 
     Cnt<COUNT> cnt;
     const F3 bg{fa.bg[0], fa.bg[1], fa.bg[2]};
-    for (;;) { // ======================= tile loop =======================
-#if RT_WF_PERSISTENT
-        if (tid == 0) {
-            *s_tile = (uint32_t) (next_tile < fa.n_tiles ? next_tile : fa.n_tiles);
-            if (next_tile < fa.n_tiles) next_tile = atomicAdd(&counters[CTR_TILE], 1ull); // prefetch: used next iteration
-        }
-        lds_barrier(); // also publishes t0p (first iteration) and separates tiles
-        const uint32_t tile = *s_tile;
-        if (tile >= fa.n_tiles) break;
-#else
-        lds_barrier();
+    {
         const uint32_t tile = blockIdx.x;
-#endif
 
         // pixel of this lane: tile row-major, 16 pixels per row -> a wave covers a 16 x 4 block of the tile
         const uint32_t tile_x = tile % fa.tiles_x, tile_y = tile / fa.tiles_x;
@@ -724,7 +698,7 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
 
         F3 res = bg;
         D3 o{fa.origin[0], fa.origin[1], fa.origin[2]};
-        D3 dir = primary_dir(fa, (int) xc, (int) y);
+        D3 dir = primary_dir_tab(fa, camx[xc], camy[y]);
         bool live = inside; // this pixel still has a ray to trace
         bool first = true;
         float cur_ratio = 1.0f;
@@ -733,7 +707,7 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
 
         RT_STAMP(1);
         for (;;) { // ----------------------- rounds -----------------------
-            // ---------------- phase A: nearest hit, compaction ----------------
+            // ---------------- phase A: nearest hit ----------------
             double best_t;
             int best;
             {
@@ -741,42 +715,56 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
                 mono_set_o<NEED_CROSS>(m, o);
                 mono_set_d<NEED_CROSS>(m, dir);
                 mono_set_od<NEED_CROSS>(m);
-                if (first) nearest<COUNT, HAS_GQ, HAS_CUBIC, true>(fa, S, gobj, m, live, lane, best_t, best, cnt);
+                if (first) nearest<COUNT, HAS_GQ, HAS_CUBIC, true>(fa, G, gobj, m, live, lane, best_t, best, cnt);
                 else nearest<COUNT, HAS_GQ, HAS_CUBIC, false>(fa, S, gobj, m, live, lane, best_t, best, cnt);
             }
             RT_STAMP(2);
             if (live) cnt.add(3, fa.n_obj);
             const bool hit = live && best >= 0;
-            uint32_t my_slot = 0;
             if (live && !hit) { // the ray leaves the scene (src/update-cpu.cpp:93-95,112-115)
                 if (!first) blend(res, cur_ratio, bg);
                 live = false;
             }
-            {
-                const unsigned long long hm = __ballot(hit);
-                uint32_t slot0 = 0;
-                if (lane == 0 && hm) slot0 = atomicAdd(s_nhits, (uint32_t) __popcll(hm));
-                slot0 = __builtin_amdgcn_readfirstlane(slot0);
-                if (hit) {
-                    const D3 sp{o.x + best_t * dir.x, o.y + best_t * dir.y, o.z + best_t * dir.z};
-                    const D3 sn = normal_vector(S.obj[best].c, sp);
-                    cnt.add(4);
-                    my_slot = slot0 + (uint32_t) __popcll(hm & ((1ull << lane) - 1ull));
-                    hp[my_slot] = sp.x; hp[WG + my_slot] = sp.y; hp[2 * WG + my_slot] = sp.z;
-                    hn[my_slot] = sn.x; hn[WG + my_slot] = sn.y; hn[2 * WG + my_slot] = sn.z;
-                    hidx[my_slot] = (uint32_t) best;
-                    hpix[my_slot] = tid;
-                }
+            D3 sp{0.0, 0.0, 0.0}, sn{0.0, 0.0, 1.0};
+            if (hit) {
+                sp = D3{o.x + best_t * dir.x, o.y + best_t * dir.y, o.z + best_t * dir.z};
+                sn = normal_vector(first ? gobj[best].c : S.obj[best].c, sp);
+                cnt.add(4);
             }
+            // ---------------- compaction of the tile's hits into the LDS queue ----------------
+            const unsigned long long hm = __ballot(hit);
+            if (lane == 0) s_wcount[wave] = (uint32_t) __popcll(hm);
             RT_STAMP(3);
             lds_barrier();
             RT_STAMP(4);
-            const uint32_t n_hits = *s_nhits;
+            const uint32_t c0 = s_wcount[0], c1 = s_wcount[1], c2 = s_wcount[2], c3 = s_wcount[3];
+            const uint32_t n_hits = c0 + c1 + c2 + c3;
+            if (n_hits == 0) break; // workgroup-uniform: nothing left to shade or bounce (all lanes are dead by now)
             const uint32_t n_chunks = (n_hits + 63) >> 6;
-
-            // ---------------- phase A': chunk bounding balls, clear shadow bits ----------------
+            if (!staged) { // first round with hits: bring the scene and the lights into LDS, 16 B per lane per step
+                const uint4 *src = reinterpret_cast<const uint4 *>(gscene);
+                uint4 *dst = reinterpret_cast<uint4 *>(smem + L.scene);
+                const uint32_t n16 = fa.scene_bytes / 16;
+                for (uint32_t i = tid; i < n16; i += WG) dst[i] = src[i];
+                const uint4 *lsrc = reinterpret_cast<const uint4 *>(glight);
+                uint4 *ldst = reinterpret_cast<uint4 *>(smem + L.light);
+                const uint32_t l16 = fa.n_lights * (uint32_t) (sizeof(DevLight) / 16);
+                for (uint32_t i = tid; i < l16; i += WG) ldst[i] = lsrc[i];
+                staged = true;
+            }
+            uint32_t my_slot = 0;
+            if (hit) {
+                my_slot = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u) + (uint32_t) __popcll(hm & ((1ull << lane) - 1ull));
+                hp[my_slot] = sp.x; hp[WG + my_slot] = sp.y; hp[2 * WG + my_slot] = sp.z;
+                hn[my_slot] = sn.x; hn[WG + my_slot] = sn.y; hn[2 * WG + my_slot] = sn.z;
+                hidx[my_slot] = (uint32_t) best;
+                hpix[my_slot] = tid;
+            }
             if (tid < n_hits)
                 for (uint32_t w = 0; w < L.shadow_words; w++) sshadow[tid * L.shadow_words + w] = 0;
+            lds_barrier();
+
+            // ---------------- phase A': chunk bounding balls ----------------
             if (wave < n_chunks) { // wave-uniform
                 const bool v = tid < n_hits;
                 const double px = v ? hp[tid] : 0.0, py = v ? hp[WG + tid] : 0.0, pz = v ? hp[2 * WG + tid] : 0.0;
@@ -807,10 +795,8 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
                 const uint32_t hs = valid ? h : c * 64;
                 const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]};
                 Mono sm;
-                {
-                    const D3 n{hn[hs], hn[WG + hs], hn[2 * WG + hs]};
-                    mono_set_o<NEED_CROSS>(sm, D3{p.x + SHADOW_BIAS * n.x, p.y + SHADOW_BIAS * n.y, p.z + SHADOW_BIAS * n.z});
-                }
+                const D3 nrm{hn[hs], hn[WG + hs], hn[2 * WG + hs]};
+                mono_set_o<NEED_CROSS>(sm, D3{p.x + SHADOW_BIAS * nrm.x, p.y + SHADOW_BIAS * nrm.y, p.z + SHADOW_BIAS * nrm.z});
                 const Ball ball = sball[c];
                 CullPre pre{};
                 if (fa.cull) pre = cull_prepare(S.us, fa.n_us, ball, lane);
@@ -832,7 +818,16 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
                     }
                     mono_set_od<NEED_CROSS>(sm);
                     if (valid) cnt.add(1);
-                    const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC>(fa, S, gobj, sm, max_t, valid, ball, pre, lt, lane, cnt);
+                    // A directional light behind the surface contributes exactly +0 whether or not it is shadowed:
+                    // surface_color multiplies by max(0.0f, (float) dot(n, light.p)) (include/light_impl.h:43), and the
+                    // colour it scales is finite.  Such lanes sit the shadow test out.  (COUNT builds test them anyway:
+                    // the reference-equivalent test count needs the index of the first blocker.)
+                    bool wanted = valid;
+                    if (!COUNT && !lt.spherical) {
+                        const float lam = (float) dot3(nrm, D3{lt.p[0], lt.p[1], lt.p[2]});
+                        wanted = valid && (0.0f < lam);
+                    }
+                    const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC>(fa, S, gobj, sm, max_t, wanted, ball, pre, lt, lane, cnt);
                     if (valid) {
                         // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
                         cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
@@ -850,13 +845,13 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
                 const D3 p{hp[h], hp[WG + h], hp[2 * WG + h]};
                 const D3 n{hn[h], hn[WG + h], hn[2 * WG + h]};
                 const DevObject *ob = &S.obj[hidx[h]];
-                const F3 albedo{ob->albedo[0], ob->albedo[1], ob->albedo[2]};
+                const F3 aop{ob->albedo[0] / PI_F, ob->albedo[1] / PI_F, ob->albedo[2] / PI_F}; // object_color / pi, once per hit
                 F3 acc{0.0f, 0.0f, 0.0f};
                 for (uint32_t l = 0; l < fa.n_lights; l++) {
                     const bool blocked = (sshadow[h * L.shadow_words + (l >> 5)] >> (l & 31)) & 1u;
                     if (!blocked) {
                         const DevLight &lt = S.light[l];
-                        F3 col = surface_color(lt.p, lt.color, lt.spherical != 0, p, n, albedo);
+                        F3 col = surface_color_pre(lt.p, lt.color, lt.spherical != 0, p, n, aop);
                         acc.x += col.x;
                         acc.y += col.y;
                         acc.z += col.z;
@@ -869,7 +864,6 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
             }
             RT_STAMP(8);
             lds_barrier();
-            if (tid == 0) *s_nhits = 0;
 
             // ---------------- phase D: blend, set up the bounce ----------------
             if (hit) {
@@ -896,8 +890,8 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
                 }
             }
             first = false; // wave-uniform: round 0 is over for everybody
-            // any pixel of the tile still bouncing?  one flag per wave, one barrier (which also orders the s_nhits
-            // reset and the queue reads before the next round)
+            // any pixel of the tile still bouncing?  one flag per wave, one barrier (which also orders the queue
+            // reads of this round before the next round's writes)
             const unsigned long long live_mask = __ballot(live); // all lanes vote, then lane 0 publishes
             if (lane == 0) s_live[wave] = live_mask != 0ull ? 1u : 0u;
             lds_barrier();
@@ -920,49 +914,35 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
             }
         }
         RT_STAMP(10);
-#if !RT_WF_PERSISTENT
-        break;
-#endif
     }
 
-#if RT_WF_PERSISTENT
-    // scheduler hygiene: the last workgroup out zeroes both words for the next launch / graph replay
-    if (tid == 0) {
-        const unsigned long long done = atomicAdd(&counters[CTR_DONE], 1ull);
-        if (done == (unsigned long long) gridDim.x - 1ull) {
-            atomicExch(&counters[CTR_TILE], 0ull);
-            atomicExch(&counters[CTR_DONE], 0ull);
-        }
-    }
-#endif
     RT_STAMP_FLUSH(counters, lane);
     cnt.flush(counters);
 }
 
+
 } // namespace RT_SYM(rtw)
 
-extern "C" size_t RT_SYM(rt_wavefront_lds_bytes)(uint32_t scene_bytes, uint32_t n_lights, uint32_t n_tab)
+extern "C" size_t RT_SYM(rt_wavefront_lds_bytes)(uint32_t scene_bytes, uint32_t n_lights)
 {
-    return RT_SYM(rtw)::LdsLayout(scene_bytes, n_lights, n_tab).total;
+    return RT_SYM(rtw)::LdsLayout(scene_bytes, n_lights).total;
 }
 
-// `grid_cap`: number of workgroups the device can keep resident (CUs x workgroups per CU), computed once by rt_create.
+// One workgroup per 16x16 tile; the dispatcher hands tiles to CUs as they free up, which is the dynamic load
+// balancing this workload needs (a tile full of hits costs ~20x an empty one).  Two persistent-workgroup variants
+// were measured and dropped: a global tile counter serialises at ~90 same-address atomics/us (8160 tiles -> 93 us),
+// static striding does not balance ("Experiments that did not pay").
 extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const DevObject *gobj, const DevLight *glight,
-                                                   void *fb, unsigned long long *counters, int count, uint32_t grid_cap,
-                                                   hipStream_t stream)
+                                                   void *fb, unsigned long long *counters, int count,
+                                                   const double *camx, const double *camy, hipStream_t stream)
 {
     using namespace RT_SYM(rtw);
     if (fa->n_tiles == 0) return hipSuccess;
-#if RT_WF_PERSISTENT
-    const dim3 grid(fa->n_tiles < grid_cap ? fa->n_tiles : grid_cap), block(WG);
-#else
-    (void) grid_cap;
     const dim3 grid(fa->n_tiles), block(WG);
-#endif
-    const size_t lds = LdsLayout(fa->scene_bytes, fa->n_lights, fa->n_tab).total;
+    const size_t lds = LdsLayout(fa->scene_bytes, fa->n_lights).total;
     const unsigned char *gs = reinterpret_cast<const unsigned char *>(gobj);
     const int sel = (count ? 4 : 0) | (fa->n_gq ? 2 : 0) | (fa->n_cub ? 1 : 0);
-#define RT_LAUNCH(C, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q>), grid, block, lds, stream, *fa, gs, glight, fb, counters)
+#define RT_LAUNCH(C, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q>), grid, block, lds, stream, *fa, gs, glight, fb, counters, camx, camy)
     switch (sel) {
     case 0: RT_LAUNCH(false, false, false); break;
     case 1: RT_LAUNCH(false, false, true); break;
@@ -975,15 +955,4 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
     }
 #undef RT_LAUNCH
     return hipGetLastError();
-}
-
-// workgroups of this kernel that fit on one CU (for sizing the persistent grid)
-extern "C" hipError_t RT_SYM(rt_wavefront_blocks_per_cu)(uint32_t scene_bytes, uint32_t n_lights, uint32_t n_tab, int has_gq,
-                                                          int has_cubic, int *out)
-{
-    using namespace RT_SYM(rtw);
-    const size_t lds = LdsLayout(scene_bytes, n_lights, n_tab).total;
-    const void *fn = has_cubic ? (has_gq ? (const void *) wavefront_tile_kernel<false, true, true> : (const void *) wavefront_tile_kernel<false, false, true>)
-                               : (has_gq ? (const void *) wavefront_tile_kernel<false, true, false> : (const void *) wavefront_tile_kernel<false, false, false>);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, (int) WG, lds);
 }

@@ -240,7 +240,7 @@ def test_culling_and_kernel_variants_agree_on_random_scenes(pkg, oracle, seed):
     b = render_desc(pkg, sc, cam, flags=pkg.RT_FLAG_NOCULL)
     c = render_desc(pkg, sc, cam, flags=pkg.RT_FLAG_SIMPLE)
     assert np.array_equal(a, b), "culling changed pixels"
-    assert np.array_equal(a, c), "wavefront and simple kernels disagree"
+    assert np.array_equal(a, c), "default path and simple kernel disagree"
     want = oracle_from(pkg, oracle, sc).render(cam=cam, nthreads=8)
     assert np.array_equal(a[..., :3], want)
 

@@ -68,6 +68,9 @@ constexpr uint32_t WG = 256; // threads per workgroup = pixels per tile
 #ifndef RT_WF_OCC
 #define RT_WF_OCC 3
 #endif
+#ifndef RT_WF_CAMTAB
+#define RT_WF_CAMTAB 1
+#endif
 
 
 // counters[]: 0 primary 1 shadow 2 reflect 3 tests (reference-equivalent, valid with cull = 0) 4 hits
@@ -698,7 +701,11 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
 
         F3 res = bg;
         D3 o{fa.origin[0], fa.origin[1], fa.origin[2]};
+#if RT_WF_CAMTAB
         D3 dir = primary_dir_tab(fa, camx[xc], camy[y]);
+#else
+        D3 dir = primary_dir(fa, (int) xc, (int) y);
+#endif
         bool live = inside; // this pixel still has a ray to trace
         bool first = true;
         float cur_ratio = 1.0f;

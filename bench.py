@@ -72,6 +72,24 @@ def algorithmic_flops(cnt, classes):
             cnt["reflect_rays"] * FLOPS["reflect_ray"] + cnt["hits"] * FLOPS["hit"])
 
 
+def pmc_traffic_bytes(args, world):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_final_pmc_summary.txt:
+    separate rocprofv3 --pmc runs of this same command; FETCH_SIZE / WRITE_SIZE are in KiB, FETCH_SIZE doubled as the
+    MI355X guide prescribes for gfx950).  Only valid for the default single-GPU workload the passes were taken on."""
+    if world != 1 or args.workload != "config2" or args.kernel != "wavefront" or args.mode != "strict":
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.txt")
+    try:
+        vals = {}
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 3 and f[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[f[0]] = float(f[2])
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+
+
 def object_classes(arr):
     out = []
     for c in arr["coefs"]:
@@ -153,20 +171,47 @@ def main():
     ren = pkg.Renderer(scene, device=local_rank, rank=rank, world=world, band_rows=band, flags=flags)
     mx = ren.max_local_rows
     stream = torch.cuda.current_stream(dev)
-    local = torch.empty((mx, W, 4), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world, mx, W, 4), dtype=torch.float32, device=dev) if (rank == 0 and world > 1) else None
-    full = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if (rank == 0 and world > 1) else None
+    root = rank == 0
+    # double-buffered so that the gather / reassembly of frame k overlaps the rendering of frame k+1 (N > 1)
+    local = [torch.empty((mx, W, 4), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    gathered = [torch.empty((world, mx, W, 4), dtype=torch.float32, device=dev) for _ in range(2)] if (root and world > 1) else None
+    full = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2)] if (root and world > 1) else None
+    side = torch.cuda.Stream(device=dev) if world > 1 else None      # root: waits for the gather, reassembles
+    works = [None, None]
+    asm_done = [torch.cuda.Event(), torch.cuda.Event()] if world > 1 else None
+    state = {"k": 0}
 
     def step():
-        ren.update(cam, dev_fb=local.data_ptr(), stream=stream.cuda_stream, timed=False)
-        if world > 1:
-            if args.backend == "nccl":
-                g = pkg.gather_to_root(local, world, rank, gathered=gathered)
-            else:  # rehearsal only: host-staged gather
-                gc = pkg.gather_to_root(local.cpu(), world, rank)
-                g = gathered.copy_(gc) if rank == 0 else None
-            if rank == 0:
-                ren.assemble(g.data_ptr(), full.data_ptr(), stream=stream.cuda_stream)
+        k = state["k"]
+        state["k"] = k + 1
+        if world == 1:
+            ren.update(cam, dev_fb=local[0].data_ptr(), stream=stream.cuda_stream, timed=False)
+            return
+        b = k & 1
+        if works[b] is not None:
+            works[b].wait()                     # frame k-2 has left local[b] (stream-side wait for NCCL, host wait for gloo)
+            if root:
+                stream.wait_event(asm_done[b])  # ... and rank 0 has reassembled it out of gathered[b]
+        ren.update(cam, dev_fb=local[b].data_ptr(), stream=stream.cuda_stream, timed=False)
+        if args.backend == "nccl":
+            # RCCL gather over xGMI, the only collective of the path; async: the next frame's render is enqueued behind
+            # this call without waiting for it
+            works[b] = dist.gather(local[b], list(gathered[b].unbind(0)) if root else None, dst=0, async_op=True)
+        else:  # rehearsal only: host-staged gather through gloo
+            lc = local[b].cpu()
+            gl = [torch.empty_like(lc) for _ in range(world)] if root else None
+            works[b] = dist.gather(lc, gl, dst=0, async_op=True)
+            works[b].wait()
+            if root:
+                gathered[b].copy_(torch.stack(gl))
+        if root:
+            with torch.cuda.stream(side):
+                if args.backend == "nccl":
+                    works[b].wait()
+                else:
+                    side.wait_stream(stream)
+                ren.assemble(gathered[b].data_ptr(), full[b].data_ptr(), stream=side.cuda_stream)
+                asm_done[b].record(side)
 
     for _ in range(args.warmup):
         step()
@@ -195,14 +240,15 @@ def main():
     if world == 1:
         kernel_ms = ev_ms / args.steps
     else:
-        kernel_ms = float(np.mean([ren.update(cam, dev_fb=local.data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(10)]))
+        kernel_ms = float(np.mean([ren.update(cam, dev_fb=local[0].data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(10)]))
 
     # outside the timed region: the reassembled N-rank frame must equal a single-context render of the same scene
     frame_check = None
     if world > 1 and rank == 0 and W * H <= 3840 * 2160:
         ref = pkg.Renderer(scene, device=local_rank, flags=flags)
         ref.update(cam)
-        frame_check = bool(np.array_equal(ref.download(), full.cpu().numpy()))
+        last = (state["k"] - 1) & 1
+        frame_check = bool(np.array_equal(ref.download(), full[last].cpu().numpy()))
         ref.cleanup_update()
 
     result = None
@@ -232,7 +278,7 @@ def main():
             # bound: the FP64 vector (VALU) pipe -- no dense contraction exists in this path, so no MFMA; HBM traffic is
             # the 16 B/pixel framebuffer write only.  `achieved` counts the operations the kernel's own algorithm executes.
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(args, world), "traffic_unit": "bytes/launch (PMC)",
                          "kernel": "trace_tile_kernel" if args.kernel == "simple" else "wavefront_tile_kernel",
                          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_launch,
                          "work_units_per_launch": {k: local_cnt[k] for k in keys},

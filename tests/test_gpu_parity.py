@@ -265,3 +265,87 @@ def test_counters_identical_across_kernels(pkg):
     for k in ("primary_rays", "shadow_rays", "reflect_rays", "tests", "hits"):
         assert out[0][k] == out[1][k] == out[2][k], (k, out)
     assert out[0]["tests_executed"] < out[1]["tests_executed"]  # culling removes work
+
+
+def _check_against_oracle(pkg, oracle, sc, cam=None, exact=True):
+    got = render_desc(pkg, sc, cam)
+    assert np.array_equal(got, render_desc(pkg, sc, cam, flags=pkg.RT_FLAG_SIMPLE))
+    assert np.array_equal(got, render_desc(pkg, sc, cam, flags=pkg.RT_FLAG_NOCULL))
+    want = oracle_from(pkg, oracle, sc).render(cam=cam, nthreads=4)
+    if exact:
+        assert np.array_equal(got[..., :3], want)
+    else:
+        assert compare(got[..., :3], want)["n_bad_pixels"] <= 2
+    return got
+
+
+def test_edge_cases(pkg, oracle):
+    """Empty and ragged inputs: no objects, no lights, 1x1 and odd-sized images, more than 32 lights (two shadow
+    words), more than 64 spheres (two table groups), a camera inside a sphere, a point light inside a sphere."""
+    # no objects at all: every pixel is background
+    s = pkg.Scene.new(37, 19, 50.0, 2, (0.3, 0.6, 0.9))
+    s.add_light("directional", [0, -1, 0])
+    g = _check_against_oracle(pkg, oracle, s)
+    assert np.allclose(g[..., :3], [0.3, 0.6, 0.9])
+    # objects but no lights: hits are black (src/update-cpu.cpp:58,77)
+    s = pkg.Scene.new(33, 17, 50.0, 2, (0.3, 0.6, 0.9))
+    s.add_object(pkg.surface_make("sphere", [0, 0, 10], [3.0]), (1, 1, 1))
+    g = _check_against_oracle(pkg, oracle, s)
+    assert g[8, 16, 0] == 0.0 and g[0, 0, 2] == np.float32(0.9)
+    # 1x1 image, 3x1 image
+    for w, h in ((1, 1), (3, 1), (1, 5)):
+        s = random_scene(pkg, 5, 6, 3, w=w, h=h)
+        _check_against_oracle(pkg, oracle, s)
+    # 40 lights (two 32-bit shadow words per hit), 70 + 1 objects (two 64-entry table groups), mirrors on
+    s = random_scene(pkg, 21, 70, 40, w=96, h=64, mirrors=True)
+    _check_against_oracle(pkg, oracle, s)
+    # camera inside a big sphere (every primary ray hits from inside; normals are not flipped, SURVEY.md Q8)
+    s = pkg.Scene.new(64, 48, 60.0, 2, (0.1, 0.1, 0.1))
+    s.add_object(pkg.surface_make("sphere", [0, 0, 0], [50.0]), (0.9, 0.8, 0.7))
+    s.add_object(pkg.surface_make("sphere", [1, 0, 8], [1.0]), (0.2, 0.9, 0.2), 0.5)
+    s.add_light("spherical", [0, 5, 4], (1, 1, 1), 500.0)
+    s.add_light("directional", [0.2, -1, 0.3], (1, 1, 1), 1.0)
+    _check_against_oracle(pkg, oracle, s)
+    # point light inside one of the spheres, spheres touching / overlapping
+    s = pkg.Scene.new(80, 60, 45.0, 3, (0.0, 0.0, 0.0))
+    for c, r in (([0, 0, 10], 2.0), ([2.0, 0, 10], 2.0), ([4.0, 0, 10], 2.0), ([0, 4.0, 10], 2.0), ([0, -4, 12], 2.5), ([8, 1, 14], 3.0)):
+        s.add_object(pkg.surface_make("sphere", c, [r]), (0.8, 0.8, 0.8), 0.3)
+    s.add_light("spherical", [0, 0, 10], (1, 1, 1), 300.0)
+    s.add_light("spherical", [3, 6, 2], (1, 0.5, 0.5), 600.0)
+    _check_against_oracle(pkg, oracle, s)
+
+
+def test_huge_coordinates_do_not_break_culling(pkg, oracle):
+    """The culling margins carry a term for the cancellation error of the reference's own t0 at large coordinates:
+    a sphere field translated by 1e6 still renders exactly like the simple kernel and the oracle."""
+    rng = np.random.default_rng(3)
+    off = np.array([1.0e6, -2.0e6, 3.0e6])
+    s = pkg.Scene.new(96, 72, 50.0, 2, (0.1, 0.2, 0.3))
+    for i in range(12):
+        c = rng.uniform([-8, -5, 8], [8, 5, 30]) + off
+        s.add_object(pkg.surface_make("sphere", c, [float(rng.uniform(0.5, 2.5))]), rng.uniform(0, 1, 3))
+    s.add_light("directional", [0.3, -1.0, 0.4], (1, 1, 1), 1.0)
+    s.add_light("spherical", np.array([0.0, 12.0, 5.0]) + off, (1, 1, 1), 800.0)
+    cam = np.eye(4).reshape(16).copy()
+    cam[12:15] = off  # camera translated with the scene (column-major: last column)
+    _check_against_oracle(pkg, oracle, s, cam=cam)
+
+
+def test_general_quadrics_and_planes(pkg, oracle):
+    """Ellipsoid, hyperboloid (negative leading coefficient: Q5 quirk), paraboloid, cross terms, planes: the GQ / LIN
+    table paths of the wavefront kernel."""
+    s = pkg.Scene.new(120, 90, 55.0, 3, (0.2, 0.3, 0.4))
+    q = np.zeros(20); q[10], q[11], q[12], q[19] = 1.0, 4.0, 0.5, -9.0; q[18] = -6.0       # ellipsoid-ish, shifted in z
+    s.add_object(q, (0.9, 0.3, 0.3))
+    q = np.zeros(20); q[10], q[11], q[12], q[19] = -1.0, 1.0, -1.0, 1.0; q[16], q[18] = 0.5, 12.0  # hyperboloid, t2 < 0 on many rays
+    s.add_object(q, (0.3, 0.9, 0.3), 0.4)
+    q = np.zeros(20); q[10], q[12], q[17], q[19] = 0.1, 0.1, 1.0, 20.0                     # the paraboloid of quadratic.yml
+    s.add_object(q, (0.8, 0.8, 0.0))
+    q = np.zeros(20); q[10], q[11], q[12], q[13], q[14], q[15], q[19] = 1.0, 2.0, 1.5, 0.5, -0.3, 0.2, -30.0; q[18] = -10.0
+    s.add_object(q, (0.3, 0.3, 0.9))                                                        # cross terms
+    s.add_object(pkg.surface_make("plane", [0, -6, 0], [0, 1, 0.05]), (0.5, 0.5, 0.5), 0.3)
+    s.add_object(pkg.surface_make("sphere", [3, 1, 9], [1.2]), (0.9, 0.9, 0.9))
+    s.add_light("directional", [0.4, -1.0, 0.3], (1, 1, 1), 1.2)
+    s.add_light("spherical", [-4, 6, 2], (1, 0.8, 0.6), 500.0)
+    for cam in (None, oracle.camera_matrix(pos=(1.0, 1.0, -3.0), yaw_deg=95.0, pitch_deg=4.0)):
+        _check_against_oracle(pkg, oracle, s, cam=cam)

@@ -332,6 +332,9 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
     fa.tiles_x = (sd->width + RT_TILE - 1) / RT_TILE;
     fa.n_tiles = fa.tiles_x * ((ctx->local_rows + RT_TILE - 1) / RT_TILE);
     fa.rgba8 = cfg.format == RT_FMT_RGBA8 ? 1u : 0u;
+    fa.has_mirror = 0;
+    for (uint32_t i = 0; i < sd->n_objects; i++)
+        if ((double) sd->reflection[i] > 1e-7) fa.has_mirror = 1; // EPS of the reflection loop, src/update-cpu.cpp:101
     std::vector<DevObject> objs(sd->n_objects);
     uint32_t n_cullable = 0;
     for (uint32_t i = 0; i < sd->n_objects; i++) {

@@ -68,6 +68,9 @@ constexpr uint32_t WG = 256; // threads per workgroup = pixels per tile
 #ifndef RT_WF_OCC
 #define RT_WF_OCC 3
 #endif
+#ifndef RT_WF_OCC_NOMIRROR
+#define RT_WF_OCC_NOMIRROR 4
+#endif
 #ifndef RT_WF_CAMTAB
 #define RT_WF_CAMTAB 1
 #endif
@@ -463,56 +466,6 @@ __device__ __forceinline__ unsigned long long relevant_mask(const UsEntry *us, u
     return __ballot(rel);
 }
 
-// The light-independent half of relevant_mask for the first 64 spheres, formed ONCE per chunk: lane j keeps
-// sphere j's offset from the chunk's ball and its limit; per light only the projection on the light axis is left.
-struct CullPre {
-    double wx, wy, wz, ww; // centre - ball centre, its squared length
-    double lim, inv_r;     // limit for directional lights; 1/r for the point-light margin term
-    bool always, in_range; // not cullable (r = +inf / NaN); lane < n_us
-};
-
-__device__ __forceinline__ CullPre cull_prepare(const UsEntry *us, uint32_t n_us, const Ball &ball, uint32_t lane)
-{
-    CullPre c;
-    c.in_range = lane < n_us;
-    const UsEntry e = us[c.in_range ? lane : 0];
-    const double r = e.r;
-    c.always = !(r < INFINITY);
-    const double ccx = -0.5 * e.kx, ccy = -0.5 * e.ky, ccz = -0.5 * e.kz;
-    c.wx = ccx - ball.cx;
-    c.wy = ccy - ball.cy;
-    c.wz = ccz - ball.cz;
-    c.ww = c.wx * c.wx + c.wy * c.wy + c.wz * c.wz;
-    const double w1 = fabs(c.wx) + fabs(c.wy) + fabs(c.wz);
-    const double s2 = ccx * ccx + ccy * ccy + ccz * ccz + ball.cx * ball.cx + ball.cy * ball.cy + ball.cz * ball.cz;
-    c.inv_r = e.inv_r;
-    c.lim = r + ball.R + 1e-6 * (w1 + r + ball.R + 1.0) + 1e-12 * (s2 + 1.0) * e.inv_r;
-    return c;
-}
-
-// Same decision as relevant_mask(us, 0, min(n_us, 64), ...) from the prepared half.
-__device__ __forceinline__ unsigned long long relevant_from_pre(const CullPre &c, const Ball &ball, const DevLight &lt)
-{
-    bool rel;
-    if (!lt.spherical) {
-        const double along = c.wx * lt.sdir[0] + c.wy * lt.sdir[1] + c.wz * lt.sdir[2];
-        const double perp2 = c.ww - along * along * lt.inv_uu;
-        rel = !(perp2 > c.lim * c.lim) && !(along < -c.lim * lt.len_u);
-    } else {
-        const double ex = lt.p[0] - ball.cx, ey = lt.p[1] - ball.cy, ez = lt.p[2] - ball.cz;
-        const double ee = ex * ex + ey * ey + ez * ez;
-        const double e1 = fabs(ex) + fabs(ey) + fabs(ez);
-        const double we = c.wx * ex + c.wy * ey + c.wz * ez;
-        const double l2 = lt.p[0] * lt.p[0] + lt.p[1] * lt.p[1] + lt.p[2] * lt.p[2];
-        const double lim = c.lim + 1e-6 * e1 + 1e-12 * l2 * c.inv_r;
-        const double lim2 = lim * lim;
-        if (!(we > 0.0)) rel = !(c.ww > lim2);
-        else if (!(we < ee)) rel = !((c.ww - 2.0 * we) + ee > lim2);
-        else rel = !(c.ww * ee - we * we > lim2 * ee);
-    }
-    return __ballot(c.in_range && (c.always || rel));
-}
-
 __device__ __forceinline__ void blend(F3 &res, float ratio, const F3 &c)
 {
     // UPDATE_COLOR, src/update-cpu.cpp:100
@@ -551,8 +504,8 @@ constexpr int NO_BLOCKER = 0x7fffffff;
 // object index.  `blocker` keeps the lowest blocking index seen; without COUNT any blocker ends the search.
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC>
 __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj,
-                                              const Mono &sm, double max_t, bool valid, const Ball &ball, const CullPre &pre,
-                                              const DevLight &lt, uint32_t lane, Cnt<COUNT> &cnt)
+                                              const Mono &sm, double max_t, bool valid, const Ball &ball, const DevLight &lt,
+                                              uint32_t lane, Cnt<COUNT> &cnt)
 {
     int blocker = NO_BLOCKER;
     const bool quad = fabs(sm.u2) > EPS;
@@ -561,7 +514,10 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
         const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
         unsigned long long cand = 0;
         if (fa.cull) {
-            unsigned long long it = (base == 0) ? relevant_from_pre(pre, ball, lt) : relevant_mask(S.us, base, end, ball, lt, lane);
+            unsigned long long it = relevant_mask(S.us, base, end, ball, lt, lane);
+#ifdef RT_EXP_NOSURV
+            it = 0; // timing experiment only: nothing survives the culling
+#endif
             if (lane == 0) cnt.add(7, end - base);
             if (valid) cnt.add(6, (unsigned long long) __popcll(it));
             while (it) { // wave-uniform loop over the spheres that survived the culling
@@ -583,6 +539,10 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
             }
         }
         if (!valid) cand = 0;
+#ifdef RT_EXP_NOSOLVE
+        if (cand) blocker = 0; // timing experiment only: pretend every candidate blocks, skip the solve
+        cand = 0;
+#endif
         while (cand) {
             const int b = __builtin_ctzll(cand);
             cand &= cand - 1;
@@ -643,8 +603,11 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
     return blocker;
 }
 
-template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC>
-__global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_tile_kernel(const FrameArgs fa, const unsigned char *__restrict__ gscene,
+// HAS_MIRROR = some object has reflection_ratio > EPS.  Without mirrors every pixel is finished after round 0, the
+// round loop is known to run once and the bounce state (ray direction, blend ratio, depth) is dead during the shadow
+// phase -- which is what lets the mirror-free instantiation fit 128 VGPRs (4 waves per SIMD).
+template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR>
+__global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : (HAS_MIRROR ? RT_WF_OCC : RT_WF_OCC_NOMIRROR))) void wavefront_tile_kernel(const FrameArgs fa, const unsigned char *__restrict__ gscene,
                                                               const DevLight *__restrict__ glight, void *__restrict__ fb,
                                                               unsigned long long *__restrict__ counters,
                                                               const double *__restrict__ camx, const double *__restrict__ camy)
@@ -800,19 +763,20 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
                 const uint32_t h = c * 64 + lane;
                 const bool valid = h < n_hits;
                 const uint32_t hs = valid ? h : c * 64;
-                const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]};
                 Mono sm;
                 const D3 nrm{hn[hs], hn[WG + hs], hn[2 * WG + hs]};
-                mono_set_o<NEED_CROSS>(sm, D3{p.x + SHADOW_BIAS * nrm.x, p.y + SHADOW_BIAS * nrm.y, p.z + SHADOW_BIAS * nrm.z});
+                {
+                    const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]};
+                    mono_set_o<NEED_CROSS>(sm, D3{p.x + SHADOW_BIAS * nrm.x, p.y + SHADOW_BIAS * nrm.y, p.z + SHADOW_BIAS * nrm.z});
+                }
                 const Ball ball = sball[c];
-                CullPre pre{};
-                if (fa.cull) pre = cull_prepare(S.us, fa.n_us, ball, lane);
                 for (uint32_t l = (wave + 4u - (c & 3u)) & 3u; l < fa.n_lights; l += 4) {
                     const DevLight &lt = S.light[l]; // wave-uniform LDS reads
                     double max_t;
                     if (lt.spherical) {
                         // shadow_ray, include/light_impl.h:19-21: (light - point) through FP32
                         max_t = 1.0;
+                        const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]}; // re-read: not kept in registers across lights
                         const D3 sd{(double) (float) (lt.p[0] - p.x), (double) (float) (lt.p[1] - p.y), (double) (float) (lt.p[2] - p.z)};
                         mono_set_d<NEED_CROSS>(sm, sd);
                     } else {
@@ -834,7 +798,7 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
                         const float lam = (float) dot3(nrm, D3{lt.p[0], lt.p[1], lt.p[2]});
                         wanted = valid && (0.0f < lam);
                     }
-                    const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC>(fa, S, gobj, sm, max_t, wanted, ball, pre, lt, lane, cnt);
+                    const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC>(fa, S, gobj, sm, max_t, wanted, ball, lt, lane, cnt);
                     if (valid) {
                         // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
                         cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
@@ -877,8 +841,8 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
                 const F3 oc{scolor[tid], scolor[WG + tid], scolor[2 * WG + tid]};
                 if (first) res = oc;
                 else blend(res, cur_ratio, oc);
-                const float refl = S.obj[best].refl;
-                if (!((double) refl > EPS)) {
+                const float refl = HAS_MIRROR ? S.obj[best].refl : 0.0f;
+                if (!HAS_MIRROR || !((double) refl > EPS)) {
                     live = false;
                 } else {
                     cur_ratio *= refl;
@@ -896,6 +860,7 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : RT_WF_OCC)) void wavefront_ti
                     }
                 }
             }
+            if (!HAS_MIRROR) break; // no mirrors: nothing can still be bouncing
             first = false; // wave-uniform: round 0 is over for everybody
             // any pixel of the tile still bouncing?  one flag per wave, one barrier (which also orders the queue
             // reads of this round before the next round's writes)
@@ -948,17 +913,25 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
     const dim3 grid(fa->n_tiles), block(WG);
     const size_t lds = LdsLayout(fa->scene_bytes, fa->n_lights).total;
     const unsigned char *gs = reinterpret_cast<const unsigned char *>(gobj);
-    const int sel = (count ? 4 : 0) | (fa->n_gq ? 2 : 0) | (fa->n_cub ? 1 : 0);
-#define RT_LAUNCH(C, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q>), grid, block, lds, stream, *fa, gs, glight, fb, counters, camx, camy)
+    const int sel = (count ? 8 : 0) | (fa->has_mirror ? 4 : 0) | (fa->n_gq ? 2 : 0) | (fa->n_cub ? 1 : 0);
+#define RT_LAUNCH(C, M, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q, M>), grid, block, lds, stream, *fa, gs, glight, fb, counters, camx, camy)
     switch (sel) {
-    case 0: RT_LAUNCH(false, false, false); break;
-    case 1: RT_LAUNCH(false, false, true); break;
-    case 2: RT_LAUNCH(false, true, false); break;
-    case 3: RT_LAUNCH(false, true, true); break;
-    case 4: RT_LAUNCH(true, false, false); break;
-    case 5: RT_LAUNCH(true, false, true); break;
-    case 6: RT_LAUNCH(true, true, false); break;
-    default: RT_LAUNCH(true, true, true); break;
+    case 0: RT_LAUNCH(false, false, false, false); break;
+    case 1: RT_LAUNCH(false, false, false, true); break;
+    case 2: RT_LAUNCH(false, false, true, false); break;
+    case 3: RT_LAUNCH(false, false, true, true); break;
+    case 4: RT_LAUNCH(false, true, false, false); break;
+    case 5: RT_LAUNCH(false, true, false, true); break;
+    case 6: RT_LAUNCH(false, true, true, false); break;
+    case 7: RT_LAUNCH(false, true, true, true); break;
+    case 8: RT_LAUNCH(true, false, false, false); break;
+    case 9: RT_LAUNCH(true, false, false, true); break;
+    case 10: RT_LAUNCH(true, false, true, false); break;
+    case 11: RT_LAUNCH(true, false, true, true); break;
+    case 12: RT_LAUNCH(true, true, false, false); break;
+    case 13: RT_LAUNCH(true, true, false, true); break;
+    case 14: RT_LAUNCH(true, true, true, false); break;
+    default: RT_LAUNCH(true, true, true, true); break;
     }
 #undef RT_LAUNCH
     return hipGetLastError();

@@ -76,7 +76,7 @@ def pmc_traffic_bytes(args, world):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_final_pmc_summary.txt:
     separate rocprofv3 --pmc runs of this same command; FETCH_SIZE / WRITE_SIZE are in KiB, FETCH_SIZE doubled as the
     MI355X guide prescribes for gfx950).  Only valid for the default single-GPU workload the passes were taken on."""
-    if world != 1 or args.workload != "config2" or args.kernel != "wavefront" or args.mode != "strict":
+    if world != 1 or args.workload != "config2" or args.kernel != "wavefront" or args.mode != "strict" or args.format != "rgba32f":
         return None
     path = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.txt")
     try:
@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "wavefront-nocull", "simple"],
                     help="A/B switch; the product default is the culling wavefront kernel")
     ap.add_argument("--band-rows", type=int, default=16)
+    ap.add_argument("--format", default="rgba32f", choices=["rgba32f", "rgba8"],
+                    help="framebuffer / wire format: rgba32f = the CPU back end's un-quantised floats (default, parity format); "
+                         "rgba8 = the reference CUDA back end's display format, 4x less to gather")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the product path). gloo stages the gather through host memory and lets several ranks share "
                          "one GPU: only for rehearsing the N>1 code path on a 1-GPU box")
@@ -154,9 +157,11 @@ def main():
     flags |= {"wavefront": 0, "wavefront-nocull": pkg.RT_FLAG_NOCULL, "simple": pkg.RT_FLAG_SIMPLE}[args.kernel]
     band = args.band_rows
     cam = pkg.IDENTITY
+    fmt = pkg.RT_FMT_RGBA8 if args.format == "rgba8" else pkg.RT_FMT_RGBA32F
+    px_dtype, px_bytes = (torch.uint8, 4.0) if args.format == "rgba8" else (torch.float32, 16.0)
 
     # ---- ray accounting: one counting frame (not timed) ----
-    rc = pkg.Renderer(scene, device=local_rank, rank=rank, world=world, band_rows=band, flags=flags | pkg.RT_FLAG_COUNT)
+    rc = pkg.Renderer(scene, device=local_rank, rank=rank, world=world, band_rows=band, flags=flags | pkg.RT_FLAG_COUNT, fmt=fmt)
     rc.update(cam)
     cnt = rc.counters()
     rc.cleanup_update()
@@ -168,14 +173,14 @@ def main():
     rays_per_frame = total["primary_rays"] + total["shadow_rays"] + total["reflect_rays"]
 
     # ---- the timed path ----
-    ren = pkg.Renderer(scene, device=local_rank, rank=rank, world=world, band_rows=band, flags=flags)
+    ren = pkg.Renderer(scene, device=local_rank, rank=rank, world=world, band_rows=band, flags=flags, fmt=fmt)
     mx = ren.max_local_rows
     stream = torch.cuda.current_stream(dev)
     root = rank == 0
     # double-buffered so that the gather / reassembly of frame k overlaps the rendering of frame k+1 (N > 1)
-    local = [torch.empty((mx, W, 4), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
-    gathered = [torch.empty((world, mx, W, 4), dtype=torch.float32, device=dev) for _ in range(2)] if (root and world > 1) else None
-    full = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2)] if (root and world > 1) else None
+    local = [torch.empty((mx, W, 4), dtype=px_dtype, device=dev) for _ in range(2 if world > 1 else 1)]
+    gathered = [torch.empty((world, mx, W, 4), dtype=px_dtype, device=dev) for _ in range(2)] if (root and world > 1) else None
+    full = [torch.empty((H, W, 4), dtype=px_dtype, device=dev) for _ in range(2)] if (root and world > 1) else None
     side = torch.cuda.Stream(device=dev) if world > 1 else None      # root: waits for the gather, reassembles
     works = [None, None]
     asm_done = [torch.cuda.Event(), torch.cuda.Event()] if world > 1 else None
@@ -245,7 +250,7 @@ def main():
     # outside the timed region: the reassembled N-rank frame must equal a single-context render of the same scene
     frame_check = None
     if world > 1 and rank == 0 and W * H <= 3840 * 2160:
-        ref = pkg.Renderer(scene, device=local_rank, flags=flags)
+        ref = pkg.Renderer(scene, device=local_rank, flags=flags, fmt=fmt)
         ref.update(cam)
         last = (state["k"] - 1) & 1
         frame_check = bool(np.array_equal(ref.download(), full[last].cpu().numpy()))
@@ -261,7 +266,7 @@ def main():
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
         dense_flops = total["tests"] * 290.0  # the reference's as-written count: 286 expansion + ~4 solver per test
         dense_equiv = dense_flops / (dt / args.steps) / 1e12
-        fb_bytes = float(ren.local_rows) * W * 16.0
+        fb_bytes = float(ren.local_rows) * W * px_bytes
         result = {
             "metric": "Mrays/sec, 20spheres.yml @1920x1080 (weak-scaled with --gpus)" if args.workload == "config2" else f"Mrays/sec, {args.workload}",
             "value": rays_per_frame * args.steps / dt / 1e6,
@@ -271,7 +276,7 @@ def main():
             "frames_per_s": args.steps / dt,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{scene_name}.yml {W}x{H}, camera identity, RGBA32F framebuffer", "objects": int(arr["coefs"].shape[0]),
+            "config": {"workload": f"{scene_name}.yml {W}x{H}, camera identity, {args.format.upper()} framebuffer", "objects": int(arr["coefs"].shape[0]),
                        "lights": int(arr["light_p"].shape[0]), "rays_per_frame": rays_per_frame, "tests_per_frame": total["tests"],
                        "kernel_mode": args.mode, "kernel": args.kernel,
                        "parallelism": f"rows band-cyclic x{world} (band {band}), gather to rank 0" if world > 1 else "single GPU"},

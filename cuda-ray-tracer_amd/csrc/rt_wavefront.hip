@@ -515,9 +515,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
         unsigned long long cand = 0;
         if (fa.cull) {
             unsigned long long it = relevant_mask(S.us, base, end, ball, lt, lane);
-#ifdef RT_EXP_NOSURV
-            it = 0; // timing experiment only: nothing survives the culling
-#endif
+
             if (lane == 0) cnt.add(7, end - base);
             if (valid) cnt.add(6, (unsigned long long) __popcll(it));
             while (it) { // wave-uniform loop over the spheres that survived the culling
@@ -539,10 +537,6 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
             }
         }
         if (!valid) cand = 0;
-#ifdef RT_EXP_NOSOLVE
-        if (cand) blocker = 0; // timing experiment only: pretend every candidate blocks, skip the solve
-        cand = 0;
-#endif
         while (cand) {
             const int b = __builtin_ctzll(cand);
             cand &= cand - 1;

@@ -62,12 +62,12 @@ def test_bad_arguments_are_reported_not_crashed(pkg):
 def test_product_does_not_link_or_import_the_oracle(pkg):
     """The oracle is test infrastructure: nothing under cuda-ray-tracer_amd/ or include/ may reference it."""
     bad = []
-    for base in (os.path.join(ROOT, "cuda-ray-tracer_amd"), os.path.join(ROOT, "include")):
+    for base in (os.path.join(ROOT, "cuda-ray-tracer_amd"), os.path.join(ROOT, "include"), os.path.join(ROOT, "tools")):
         for dp, dn, fn in os.walk(base):
             if "build" in dp.split(os.sep):
                 continue
             for f in fn:
-                if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
+                if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", ".sh")) or f == "Makefile":
                     t = open(os.path.join(dp, f), errors="replace").read()
                     if re.search(r"rt_oracle|librt_oracle|from oracle|import oracle|oracle/", t):
                         bad.append(os.path.join(dp, f))

@@ -1,5 +1,6 @@
 // rt_wavefront.hip -- the production render kernel for gfx950 (MI355X): a workgroup-level wavefront
-// pipeline held entirely in LDS.  Compiled twice like rt_kernels.hip (RT_VARIANT = strict | fast).
+// pipeline whose working state lives entirely in LDS.  Compiled twice like rt_kernels.hip
+// (RT_VARIANT = strict | fast).
 //
 // It computes, pixel for pixel, what the reference's render_pixel / get_color_and_object compute
 // (src/update-cpu.cpp:45-119, through include/surface_impl.h and include/light_impl.h; the
@@ -7,33 +8,37 @@
 // that reaches a pixel is rt_math.hpp's, shared with the simple kernel.  What differs is the schedule:
 //
 //   one workgroup (4 waves) owns a 16x16 pixel tile and iterates ROUNDS (round 0 = primary rays, round k =
-//   k-th mirror bounce) of five phases separated by workgroup barriers:
+//   k-th mirror bounce) of phases separated by LDS-only workgroup barriers (lds_barrier):
 //
-//   A  nearest hit   one lane per live pixel; wave-uniform loop over objects that only forms t2,t1,t0 and the
-//                    sign of the discriminant; the sqrt + divisions of the root solve are DEFERRED to a short
-//                    per-lane loop over the few objects that can hit (a 64-bit candidate mask per lane).
-//                    Hits are compacted into an LDS queue (one LDS atomic per wave, ballot + popcount).
-//   A' per 64-hit chunk: bounding ball of the chunk's hit points (wave min/max reduction); shadow masks zeroed.
-//   B  shadow rays   work item = (light, 64-hit chunk), dealt round-robin to the 4 waves, so a tile with few
-//                    hits still keeps every wave busy.  Per item the wave first CULLS: lane j decides whether
-//                    sphere j can possibly touch any shadow ray of the chunk (distance of its centre to the
-//                    chunk's swept bounding volume, with a generous margin -- purely conservative, see
-//                    relevant_mask); the ballot of that is a wave-uniform object mask.  Then the same
-//                    two-step test as in A over the surviving objects only.  One bit per (hit, light) in LDS.
+//   A  nearest hit   one lane per live pixel.  Primary rays: unit spheres are first culled against the wave's
+//                    16x4-pixel ray cone (primary_cone_mask).  Wave-uniform loops over the per-class tables only
+//                    form t1, t0 and the sign of the discriminant; the sqrt + divisions of the root solve are
+//                    DEFERRED to a short per-lane loop over the few objects that can hit (a 64-bit candidate mask
+//                    per lane).  Hits are compacted into an LDS queue (ballot prefix + per-wave counts).
+//                    A tile whose round finds no hit at all stops here: one barrier, store, done.
+//   A' hits          first round with hits: stage the scene + lights into LDS.  Per 64-hit chunk: bounding ball of
+//                    the chunk's hit points (DPP min/max reductions).
+//   B  shadow rays   every wave visits every chunk and takes the lights == (wave - chunk) mod 4.  Per (chunk,
+//                    light) the wave first CULLS: lane j decides whether sphere j can possibly touch any shadow ray
+//                    of the chunk (distance of its centre to the chunk's swept bounding volume, with a generous
+//                    margin -- purely conservative, see relevant_mask); the ballot of that is a wave-uniform object
+//                    mask.  Then the same two-step test as in A over the surviving objects only.  One bit per
+//                    (hit, light) in LDS.
 //   C  shading       one lane per hit: lights in order, Lambert term for the unshadowed ones, FP32 accumulate,
 //                    clamp (src/update-cpu.cpp:57-78).
 //   D  blend/bounce  the pixel's owner lane blends the colour into its running result and, for mirrors, sets
-//                    up the next round's ray (src/update-cpu.cpp:96-117).
+//                    up the next round's ray (src/update-cpu.cpp:96-117).  One flag per wave + one barrier tell
+//                    whether any pixel of the tile is still bouncing.
 //
-//   The loop ends when __syncthreads_or says no pixel of the tile is still bouncing; every lane then stores
-//   its pixel (16-byte RGBA32F or 4-byte RGBA8, rows of the tile contiguous).
+//   Every lane finally stores its pixel (16-byte RGBA32F or 4-byte RGBA8, rows of the tile contiguous).
 //
-// The scene (object records + one packed table per surface class, rt_scene_dev.h) is staged into LDS once per
-// workgroup.  Wave-uniform loops read the class tables with unconditional LDS broadcast reads (LDS returns in
-// order, so unrolled iterations overlap their reads with arithmetic; the first version of this kernel read the
-// object array through scalar loads behind a class branch and spent ~500 cycles per object on serialized
-// s_load round trips -- profiles/r01_*).  Reads with a per-lane index (deferred solves, normals, albedo) gather
-// from the same LDS copy.  Scenes without degree-3 surfaces run an instantiation that contains no cubic code.
+// Scene data (rt_scene_dev.h: object records + one packed table per surface class + lights) is read straight from
+// global memory in round 0 -- wave-uniform indices become scalar loads, and 83 % of the tiles of a typical frame never
+// need more than that -- and from an LDS copy afterwards: unconditional LDS broadcast reads for wave-uniform loops
+// (LDS returns in order, so unrolled iterations overlap reads with arithmetic), per-lane gathers for deferred solves,
+// normals and albedo.  The kernel is instantiated per scene feature (general quadrics, degree-3 surfaces, mirrors):
+// an instantiation contains no code and no registers for a feature the scene does not have; the mirror-free
+// sphere/plane one fits 94 VGPRs (5 waves per SIMD).  DESIGN.md section 5 has the measurements behind each choice.
 #include <hip/hip_runtime.h>
 
 #include "rt_math.hpp"
@@ -76,7 +81,7 @@ constexpr uint32_t WG = 256; // threads per workgroup = pixels per tile
 #endif
 
 
-// counters[]: 0 primary 1 shadow 2 reflect 3 tests (reference-equivalent, valid with cull = 0) 4 hits
+// counters[]: 0 primary 1 shadow 2 reflect 3 tests (reference-equivalent: what the reference would have run) 4 hits
 //             5 solves executed 6 tests executed 7 cull evaluations
 template <bool COUNT>
 struct Cnt {
@@ -478,7 +483,7 @@ __host__ __device__ inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15
 
 // LDS carve-up (dynamic shared memory), shared by kernel and launcher.
 struct LdsLayout {
-    uint32_t scene, light, hp, hn, hidx, hpix, color, shadow, ball, misc, total, shadow_words;
+    uint32_t scene, light, hp, hn, hdir, hidx, hpix, color, shadow, ball, misc, total, shadow_words;
     __host__ __device__ LdsLayout(uint32_t scene_bytes, uint32_t n_lights)
     {
         shadow_words = (n_lights + 31) / 32;
@@ -488,6 +493,7 @@ struct LdsLayout {
         light = off; off = align16(off + n_lights * (uint32_t) sizeof(DevLight));
         hp = off; off = align16(off + 3 * WG * 8);
         hn = off; off = align16(off + 3 * WG * 8);
+        hdir = off; off = align16(off + 3 * WG * 8);
         hidx = off; off = align16(off + WG * 4);
         hpix = off; off = align16(off + WG * 4);
         color = off; off = align16(off + 3 * WG * 4);
@@ -601,7 +607,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
 // round loop is known to run once and the bounce state (ray direction, blend ratio, depth) is dead during the shadow
 // phase -- which is what lets the mirror-free instantiation fit 128 VGPRs (4 waves per SIMD).
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR>
-__global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : (HAS_MIRROR ? RT_WF_OCC : RT_WF_OCC_NOMIRROR))) void wavefront_tile_kernel(const FrameArgs fa, const unsigned char *__restrict__ gscene,
+__global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_WF_OCC : RT_WF_OCC_NOMIRROR))) void wavefront_tile_kernel(const FrameArgs fa, const unsigned char *__restrict__ gscene,
                                                               const DevLight *__restrict__ glight, void *__restrict__ fb,
                                                               unsigned long long *__restrict__ counters,
                                                               const double *__restrict__ camx, const double *__restrict__ camy)
@@ -626,6 +632,7 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : (HAS_MIRROR ? RT_WF_OCC : RT_
     G.light = glight;
     double *hp = reinterpret_cast<double *>(smem + L.hp);   // [3][WG] hit points (SoA: lane-consecutive, conflict-free)
     double *hn = reinterpret_cast<double *>(smem + L.hn);   // [3][WG] hit normals
+    double *hdir = reinterpret_cast<double *>(smem + L.hdir); // [3][WG] ray direction of the pixel, parked across phases B / C (mirrors only)
     uint32_t *hidx = reinterpret_cast<uint32_t *>(smem + L.hidx); // object of hit h
     uint32_t *hpix = reinterpret_cast<uint32_t *>(smem + L.hpix); // owner lane (pixel) of hit h
     float *scolor = reinterpret_cast<float *>(smem + L.color);    // [3][WG] direct lighting of the pixel's hit this round
@@ -723,6 +730,9 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : (HAS_MIRROR ? RT_WF_OCC : RT_
                 hn[my_slot] = sn.x; hn[WG + my_slot] = sn.y; hn[2 * WG + my_slot] = sn.z;
                 hidx[my_slot] = (uint32_t) best;
                 hpix[my_slot] = tid;
+                if (HAS_MIRROR) { // the bounce needs the incoming direction again in phase D; keep it out of registers meanwhile
+                    hdir[tid] = dir.x; hdir[WG + tid] = dir.y; hdir[2 * WG + tid] = dir.z;
+                }
             }
             if (tid < n_hits)
                 for (uint32_t w = 0; w < L.shadow_words; w++) sshadow[tid * L.shadow_words + w] = 0;
@@ -848,7 +858,7 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : (HAS_MIRROR ? RT_WF_OCC : RT_
                         // hit point and normal come back from this lane's queue slot (kept out of registers across B / C)
                         const D3 sp{hp[my_slot], hp[WG + my_slot], hp[2 * WG + my_slot]};
                         const D3 sn{hn[my_slot], hn[WG + my_slot], hn[2 * WG + my_slot]};
-                        dir = reflect_ray(dir, sn);
+                        dir = reflect_ray(D3{hdir[tid], hdir[WG + tid], hdir[2 * WG + tid]}, sn);
                         cnt.add(2);
                         o = D3{sp.x + SHADOW_BIAS * sn.x, sp.y + SHADOW_BIAS * sn.y, sp.z + SHADOW_BIAS * sn.z};
                     }

@@ -27,7 +27,7 @@ RT_ERR_NO_DEVICE = -4
 ABI_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_scene_load_file", "rt_scene_new", "rt_scene_add_object",
     "rt_scene_add_light", "rt_surface_make", "rt_scene_set_size", "rt_scene_set_max_reflections",
-    "rt_scene_get_desc", "rt_scene_free", "rt_create", "rt_render", "rt_local_rows", "rt_max_local_rows",
+    "rt_scene_get_desc", "rt_scene_free", "rt_camera_matrix", "rt_create", "rt_render", "rt_local_rows", "rt_max_local_rows",
     "rt_row_map", "rt_pixel_bytes", "rt_device_fb", "rt_download", "rt_assemble", "rt_get_counters", "rt_debug_counters", "rt_destroy",
 ]
 
@@ -107,6 +107,7 @@ def lib():
         L.rt_scene_get_desc.argtypes = [vp, C.POINTER(SceneDesc)]
         L.rt_scene_free.argtypes = [vp]
         L.rt_scene_free.restype = None
+        L.rt_camera_matrix.argtypes = [dp, C.c_double, C.c_double, dp]
         L.rt_create.argtypes = [C.POINTER(vp), C.POINTER(SceneDesc), C.POINTER(Config)]
         L.rt_render.argtypes = [vp, dp, vp, vp, fp]
         L.rt_local_rows.argtypes = [vp, C.POINTER(C.c_uint32)]
@@ -208,6 +209,14 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+
+def camera_matrix(pos=(0.0, 0.0, 0.0), yaw_deg=90.0, pitch_deg=0.0):
+    """The reference host's camera_matrix() (src/ray-tracer.cpp:44-58) for a pose; 16 doubles, column-major."""
+    p = np.asarray(pos, dtype=np.float64)
+    out = np.empty(16, dtype=np.float64)
+    _check(lib().rt_camera_matrix(_dptr(p), float(yaw_deg), float(pitch_deg), _dptr(out)))
+    return out
 
 
 def surface_make(kind, a=None, b=None):

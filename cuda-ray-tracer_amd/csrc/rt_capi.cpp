@@ -17,6 +17,7 @@
 #include "rt_scene_dev.h"
 #include "scene-exception.h"
 #include "scene.h"
+#include "camera.h"
 
 // kernels, one set per floating-point contraction mode (rt_kernels.hip)
 extern "C" hipError_t rt_launch_trace_strict(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, int, hipStream_t);
@@ -247,6 +248,19 @@ extern "C" int rt_scene_get_desc(const rt_scene *s, rt_scene_desc *out)
 }
 
 extern "C" void rt_scene_free(rt_scene *s) { delete s; }
+
+extern "C" int rt_camera_matrix(const double pos[3], double yaw_deg, double pitch_deg, double out_cam[16])
+{
+    if (!pos || !out_cam) return fail(RT_ERR_INVALID, "rt_camera_matrix: null argument");
+    Camera c;
+    c.position = glm::dvec3(pos[0], pos[1], pos[2]);
+    c.yaw = yaw_deg;
+    c.pitch = pitch_deg;
+    const glm::dmat4 m = c.matrix();
+    for (int col = 0; col < 4; col++)
+        for (int row = 0; row < 4; row++) out_cam[col * 4 + row] = m[col][row];
+    return RT_OK;
+}
 
 // ---- render -------------------------------------------------------------------------------------------
 static uint32_t classify(const double *c)

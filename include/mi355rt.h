@@ -123,6 +123,11 @@ int rt_scene_set_max_reflections(rt_scene *s, uint32_t max_reflections);
 int rt_scene_get_desc(const rt_scene *s, rt_scene_desc *out);
 void rt_scene_free(rt_scene *s);
 
+/* The reference host's camera (src/ray-tracer.cpp:25-58): camera-to-world matrix
+ * inverse(lookAt(pos, pos - direction(yaw, pitch), +y)), column-major, 16 doubles -- the argument update()
+ * receives every frame.  Start-up pose (pos 0, yaw 90, pitch 0) is the identity to ~6e-17. */
+int rt_camera_matrix(const double pos[3], double yaw_deg, double pitch_deg, double out_cam[16]);
+
 /* ---------------------------------------------------------------------------------------------------
  * Rendering
  * ------------------------------------------------------------------------------------------------- */

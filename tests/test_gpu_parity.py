@@ -349,3 +349,17 @@ def test_general_quadrics_and_planes(pkg, oracle):
     s.add_light("spherical", [-4, 6, 2], (1, 0.8, 0.6), 500.0)
     for cam in (None, oracle.camera_matrix(pos=(1.0, 1.0, -3.0), yaw_deg=95.0, pitch_deg=4.0)):
         _check_against_oracle(pkg, oracle, s, cam=cam)
+
+
+def test_fly_through_sequence(pkg, oracle):
+    """A moving-camera sequence (the host loop of src/ray-tracer.cpp:220-233, headless): every frame equals the
+    oracle's frame for the same pose; one context renders the whole sequence (state does not leak between frames)."""
+    w, h = 192, 108
+    sc = pkg.Scene.load_from_file(scene_path("20spheres")).set_size(w, h)
+    osc = oracle.load_scene(scene_path("20spheres")).with_size(w, h)
+    r = pkg.Renderer(sc, device=0)
+    for i in range(8):
+        cam = pkg.camera_matrix(pos=(0.4 * i - 1.0, 0.2 * i, -0.5 * i), yaw_deg=90.0 + 3.0 * i, pitch_deg=-2.0 + 1.5 * i)
+        r.update(cam)
+        assert np.array_equal(r.download()[..., :3], osc.render(cam=cam, nthreads=8)), i
+    r.cleanup_update()

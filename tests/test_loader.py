@@ -169,3 +169,14 @@ def test_programmatic_scene_equals_loaded(pkg):
     b = s.arrays()
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_host_camera_matches_oracle(pkg, oracle):
+    """rt_camera_matrix (host/src/camera.cpp on glm_min's lookAt / inverse) against the oracle's restatement of
+    src/ray-tracer.cpp:44-58, bit for bit, incl. the start-up pose that is the identity to ~6e-17."""
+    rng = np.random.default_rng(11)
+    assert np.abs(pkg.camera_matrix() - np.eye(4).reshape(16)).max() < 1e-15
+    for _ in range(200):
+        pos = rng.normal(size=3) * 10
+        yaw, pitch = float(rng.uniform(-180, 180)), float(rng.uniform(-89, 89))
+        assert np.array_equal(pkg.camera_matrix(pos, yaw, pitch), oracle.camera_matrix(pos, yaw, pitch))

@@ -302,8 +302,6 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
     if ((sd->n_objects && (!sd->coefs || !sd->reflection || !sd->albedo)) ||
         (sd->n_lights && (!sd->light_is_spherical || !sd->light_p || !sd->light_color)))
         return fail(RT_ERR_INVALID, "rt_create: null scene array");
-    if ((size_t) sd->n_objects * sizeof(DevObject) > RT_MAX_LDS_SCENE)
-        return fail(RT_ERR_SCENE, "rt_create: %u objects exceed the %u-byte LDS scene budget", sd->n_objects, RT_MAX_LDS_SCENE);
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -418,13 +416,23 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
     fa.off_gq = (uint32_t) off; off = up16(off + sizeof(GqEntry) * t_gq.size());
     fa.off_lin = (uint32_t) off; off = up16(off + sizeof(LinEntry) * t_lin.size());
     fa.off_cub = (uint32_t) off; off = up16(off + sizeof(uint32_t) * t_cub.size());
+    fa.off_mat = (uint32_t) off; off = up16(off + sizeof(MatEntry) * objs.size());
     fa.scene_bytes = (uint32_t) (off ? off : 16);
+    fa.stage_bytes = fa.scene_bytes - fa.off_us;
     std::vector<unsigned char> blob(fa.scene_bytes, 0);
     if (!objs.empty()) std::memcpy(blob.data(), objs.data(), sizeof(DevObject) * objs.size());
     if (!t_us.empty()) std::memcpy(blob.data() + fa.off_us, t_us.data(), sizeof(UsEntry) * t_us.size());
     if (!t_gq.empty()) std::memcpy(blob.data() + fa.off_gq, t_gq.data(), sizeof(GqEntry) * t_gq.size());
     if (!t_lin.empty()) std::memcpy(blob.data() + fa.off_lin, t_lin.data(), sizeof(LinEntry) * t_lin.size());
     if (!t_cub.empty()) std::memcpy(blob.data() + fa.off_cub, t_cub.data(), sizeof(uint32_t) * t_cub.size());
+    for (size_t i = 0; i < objs.size(); i++) {
+        MatEntry m{};
+        m.albedo[0] = objs[i].albedo[0];
+        m.albedo[1] = objs[i].albedo[1];
+        m.albedo[2] = objs[i].albedo[2];
+        m.refl = objs[i].refl;
+        std::memcpy(blob.data() + fa.off_mat + i * sizeof(MatEntry), &m, sizeof(m));
+    }
     std::vector<DevLight> lights(sd->n_lights);
     for (uint32_t i = 0; i < sd->n_lights; i++) {
         DevLight &l = lights[i];
@@ -446,10 +454,10 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
         l.len_u = 1.001 * std::sqrt(l.u2);
     }
 
-    if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.scene_bytes, sd->n_lights) > 160u * 1024u) {
+    if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights) > 160u * 1024u) {
         delete ctx;
         return fail(RT_ERR_SCENE, "rt_create: scene needs %zu bytes of LDS per workgroup (limit 160 KiB)",
-                    rt_wavefront_lds_bytes_strict(fa.scene_bytes, sd->n_lights));
+                    rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights));
     }
     int rc = RT_OK;
     auto hip_ok = [&](hipError_t err, const char *what) {

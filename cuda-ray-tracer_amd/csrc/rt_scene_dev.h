@@ -60,7 +60,11 @@ struct alignas(16) GqEntry {  // any other surface of degree <= 2
     double x2, y2, z2, xy, xz, yz, kx, ky, kz, c;
     uint32_t orig, pad[3];
 };                            // 96 B
-static_assert(sizeof(UsEntry) == 64 && sizeof(LinEntry) == 48 && sizeof(GqEntry) == 96, "table layout");
+struct alignas(16) MatEntry { // per object, scene order: what shading and the bounce decision read
+    float albedo[3];          // Object::color
+    float refl;               // Object::reflection_ratio
+};                            // 16 B
+static_assert(sizeof(UsEntry) == 64 && sizeof(LinEntry) == 48 && sizeof(GqEntry) == 96 && sizeof(MatEntry) == 16, "table layout");
 
 struct alignas(16) DevLight {
     double p[3];        // LightSource::p
@@ -89,16 +93,18 @@ struct FrameArgs {
     uint32_t local_rows;
     uint32_t tiles_x;    // number of 16-pixel tile columns
     uint32_t cull;       // wavefront kernel: 1 = cull shadow tests against per-chunk bounding volumes
-    // scene blob = [DevObject x n_obj][UsEntry x n_us][GqEntry x n_gq][LinEntry x n_lin][uint32 x n_cub]
+    // scene blob = [DevObject x n_obj][UsEntry x n_us][GqEntry x n_gq][LinEntry x n_lin][uint32 x n_cub][MatEntry x n_obj]
+    // Only the part from off_us on (class tables + materials: 64-96 B per object) is ever staged into LDS; the
+    // 224-byte object records stay in global memory and are read per hit (normals) only.
     uint32_t n_us, n_gq, n_lin, n_cub;
-    uint32_t off_us, off_gq, off_lin, off_cub; // byte offsets into the blob
-    uint32_t scene_bytes;                       // blob size, multiple of 16
+    uint32_t off_us, off_gq, off_lin, off_cub, off_mat; // byte offsets into the blob
+    uint32_t scene_bytes;                                // blob size, multiple of 16
+    uint32_t stage_bytes;                                // scene_bytes - off_us
     uint32_t n_tiles;                           // tiles of this rank's rows (tiles_x * tiles_y)
     uint32_t rgba8;                             // 1: store iround(c*255) RGBA8 instead of RGBA32F
     uint32_t has_mirror;                        // some object has reflection_ratio > EPS
 };
 
 #define RT_TILE 16        // a workgroup renders a 16 x 16 pixel tile
-#define RT_MAX_LDS_SCENE (96u * 1024u)
 
 #endif

@@ -219,11 +219,11 @@ __device__ __forceinline__ void accept(double t, int k, double &best_t, int &bes
 
 // The scene as staged in LDS.
 struct SceneLds {
-    const DevObject *obj;
     const UsEntry *us;
     const GqEntry *gq;
     const LinEntry *lin;
     const uint32_t *cub;
+    const MatEntry *mat;
     const DevLight *light;
 };
 
@@ -614,17 +614,17 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool NEED_CROSS = HAS_GQ || HAS_CUBIC;
-    const LdsLayout L(fa.scene_bytes, fa.n_lights);
-    const DevObject *gobj = reinterpret_cast<const DevObject *>(gscene);
-    SceneLds S; // the scene staged in LDS (only tiles with hits ever stage it)
-    S.obj = reinterpret_cast<const DevObject *>(smem + L.scene);
-    S.us = reinterpret_cast<const UsEntry *>(smem + L.scene + fa.off_us);
-    S.gq = reinterpret_cast<const GqEntry *>(smem + L.scene + fa.off_gq);
-    S.lin = reinterpret_cast<const LinEntry *>(smem + L.scene + fa.off_lin);
-    S.cub = reinterpret_cast<const uint32_t *>(smem + L.scene + fa.off_cub);
+    const LdsLayout L(fa.stage_bytes, fa.n_lights);
+    const DevObject *gobj = reinterpret_cast<const DevObject *>(gscene); // full object records: global memory only
+    SceneLds S; // class tables + materials staged in LDS (only tiles with hits ever stage them); LDS offset = blob offset - off_us
+    S.us = reinterpret_cast<const UsEntry *>(smem + L.scene);
+    S.gq = reinterpret_cast<const GqEntry *>(smem + L.scene + (fa.off_gq - fa.off_us));
+    S.lin = reinterpret_cast<const LinEntry *>(smem + L.scene + (fa.off_lin - fa.off_us));
+    S.cub = reinterpret_cast<const uint32_t *>(smem + L.scene + (fa.off_cub - fa.off_us));
+    S.mat = reinterpret_cast<const MatEntry *>(smem + L.scene + (fa.off_mat - fa.off_us));
     S.light = reinterpret_cast<const DevLight *>(smem + L.light);
     SceneLds G; // the same tables where they live in global memory (round 0 runs straight from there)
-    G.obj = gobj;
+    G.mat = reinterpret_cast<const MatEntry *>(gscene + fa.off_mat);
     G.us = reinterpret_cast<const UsEntry *>(gscene + fa.off_us);
     G.gq = reinterpret_cast<const GqEntry *>(gscene + fa.off_gq);
     G.lin = reinterpret_cast<const LinEntry *>(gscene + fa.off_lin);
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
             D3 sp{0.0, 0.0, 0.0}, sn{0.0, 0.0, 1.0};
             if (hit) {
                 sp = D3{o.x + best_t * dir.x, o.y + best_t * dir.y, o.z + best_t * dir.z};
-                sn = normal_vector(first ? gobj[best].c : S.obj[best].c, sp);
+                sn = normal_vector(gobj[best].c, sp); // 20 coefficients of the hit object, gathered from global (L2) per hit
                 cnt.add(4);
             }
             // ---------------- compaction of the tile's hits into the LDS queue ----------------
@@ -713,9 +713,9 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
             if (n_hits == 0) break; // workgroup-uniform: nothing left to shade or bounce (all lanes are dead by now)
             const uint32_t n_chunks = (n_hits + 63) >> 6;
             if (!staged) { // first round with hits: bring the scene and the lights into LDS, 16 B per lane per step
-                const uint4 *src = reinterpret_cast<const uint4 *>(gscene);
+                const uint4 *src = reinterpret_cast<const uint4 *>(gscene + fa.off_us);
                 uint4 *dst = reinterpret_cast<uint4 *>(smem + L.scene);
-                const uint32_t n16 = fa.scene_bytes / 16;
+                const uint32_t n16 = fa.stage_bytes / 16;
                 for (uint32_t i = tid; i < n16; i += WG) dst[i] = src[i];
                 const uint4 *lsrc = reinterpret_cast<const uint4 *>(glight);
                 uint4 *ldst = reinterpret_cast<uint4 *>(smem + L.light);
@@ -819,8 +819,8 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
                 const uint32_t h = tid;
                 const D3 p{hp[h], hp[WG + h], hp[2 * WG + h]};
                 const D3 n{hn[h], hn[WG + h], hn[2 * WG + h]};
-                const DevObject *ob = &S.obj[hidx[h]];
-                const F3 aop{ob->albedo[0] / PI_F, ob->albedo[1] / PI_F, ob->albedo[2] / PI_F}; // object_color / pi, once per hit
+                const MatEntry mt = S.mat[hidx[h]];
+                const F3 aop{mt.albedo[0] / PI_F, mt.albedo[1] / PI_F, mt.albedo[2] / PI_F}; // object_color / pi, once per hit
                 F3 acc{0.0f, 0.0f, 0.0f};
                 for (uint32_t l = 0; l < fa.n_lights; l++) {
                     const bool blocked = (sshadow[h * L.shadow_words + (l >> 5)] >> (l & 31)) & 1u;
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
                 const F3 oc{scolor[tid], scolor[WG + tid], scolor[2 * WG + tid]};
                 if (first) res = oc;
                 else blend(res, cur_ratio, oc);
-                const float refl = HAS_MIRROR ? S.obj[best].refl : 0.0f;
+                const float refl = HAS_MIRROR ? S.mat[best].refl : 0.0f;
                 if (!HAS_MIRROR || !((double) refl > EPS)) {
                     live = false;
                 } else {
@@ -899,9 +899,9 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
 
 } // namespace RT_SYM(rtw)
 
-extern "C" size_t RT_SYM(rt_wavefront_lds_bytes)(uint32_t scene_bytes, uint32_t n_lights)
+extern "C" size_t RT_SYM(rt_wavefront_lds_bytes)(uint32_t stage_bytes, uint32_t n_lights)
 {
-    return RT_SYM(rtw)::LdsLayout(scene_bytes, n_lights).total;
+    return RT_SYM(rtw)::LdsLayout(stage_bytes, n_lights).total;
 }
 
 // One workgroup per 16x16 tile; the dispatcher hands tiles to CUs as they free up, which is the dynamic load
@@ -915,7 +915,7 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
     using namespace RT_SYM(rtw);
     if (fa->n_tiles == 0) return hipSuccess;
     const dim3 grid(fa->n_tiles), block(WG);
-    const size_t lds = LdsLayout(fa->scene_bytes, fa->n_lights).total;
+    const size_t lds = LdsLayout(fa->stage_bytes, fa->n_lights).total;
     const unsigned char *gs = reinterpret_cast<const unsigned char *>(gobj);
     const int sel = (count ? 8 : 0) | (fa->has_mirror ? 4 : 0) | (fa->n_gq ? 2 : 0) | (fa->n_cub ? 1 : 0);
 #define RT_LAUNCH(C, M, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q, M>), grid, block, lds, stream, *fa, gs, glight, fb, counters, camx, camy)

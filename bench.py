@@ -116,9 +116,11 @@ def main():
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "wavefront-nocull", "simple"],
                     help="A/B switch; the product default is the culling wavefront kernel")
     ap.add_argument("--band-rows", type=int, default=16)
-    ap.add_argument("--format", default="rgba32f", choices=["rgba32f", "rgba8"],
-                    help="framebuffer / wire format: rgba32f = the CPU back end's un-quantised floats (default, parity format); "
-                         "rgba8 = the reference CUDA back end's display format, 4x less to gather")
+    ap.add_argument("--format", default="auto", choices=["auto", "rgba32f", "rgba8"],
+                    help="framebuffer / wire format.  rgba32f = the CPU back end's un-quantised floats (the parity format; "
+                         "default on one GPU).  rgba8 = iround(c*255) RGBA8, the format the reference's CUDA back end writes "
+                         "(src/update-cuda.cu:149-156); default when the frame is gathered (N > 1): the gather to rank 0 is "
+                         "xGMI-bound and a float frame is 4x the bytes of the frame a display needs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the product path). gloo stages the gather through host memory and lets several ranks share "
                          "one GPU: only for rehearsing the N>1 code path on a 1-GPU box")
@@ -157,6 +159,8 @@ def main():
     flags |= {"wavefront": 0, "wavefront-nocull": pkg.RT_FLAG_NOCULL, "simple": pkg.RT_FLAG_SIMPLE}[args.kernel]
     band = args.band_rows
     cam = pkg.IDENTITY
+    if args.format == "auto":
+        args.format = "rgba32f" if world == 1 else "rgba8"
     fmt = pkg.RT_FMT_RGBA8 if args.format == "rgba8" else pkg.RT_FMT_RGBA32F
     px_dtype, px_bytes = (torch.uint8, 4.0) if args.format == "rgba8" else (torch.float32, 16.0)
 
@@ -278,7 +282,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{scene_name}.yml {W}x{H}, camera identity, {args.format.upper()} framebuffer", "objects": int(arr["coefs"].shape[0]),
                        "lights": int(arr["light_p"].shape[0]), "rays_per_frame": rays_per_frame, "tests_per_frame": total["tests"],
-                       "kernel_mode": args.mode, "kernel": args.kernel,
+                       "kernel_mode": args.mode, "kernel": args.kernel, "framebuffer_format": args.format,
                        "parallelism": f"rows band-cyclic x{world} (band {band}), gather to rank 0" if world > 1 else "single GPU"},
             # bound: the FP64 vector (VALU) pipe -- no dense contraction exists in this path, so no MFMA; HBM traffic is
             # the 16 B/pixel framebuffer write only.  `achieved` counts the operations the kernel's own algorithm executes.

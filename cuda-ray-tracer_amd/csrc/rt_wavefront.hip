@@ -776,6 +776,18 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
                 const Ball ball = sball[c];
                 for (uint32_t l = (wave + 4u - (c & 3u)) & 3u; l < fa.n_lights; l += 4) {
                     const DevLight &lt = S.light[l]; // wave-uniform LDS reads
+                    if (valid) cnt.add(1);
+                    // A directional light behind the surface contributes exactly +0 whether or not it is shadowed:
+                    // surface_color multiplies by max(0.0f, (float) dot(n, light.p)) (include/light_impl.h:43), and the
+                    // colour it scales is finite.  Such lanes sit the shadow test out, and a light that is behind EVERY
+                    // hit of the chunk costs nothing beyond this dot product.  (COUNT builds test them anyway: the
+                    // reference-equivalent test count needs the index of the first blocker.)
+                    bool wanted = valid;
+                    if (!COUNT && !lt.spherical) {
+                        const float lam = (float) dot3(nrm, D3{lt.p[0], lt.p[1], lt.p[2]});
+                        wanted = valid && (0.0f < lam);
+                        if (!__any(wanted)) continue;
+                    }
                     double max_t;
                     if (lt.spherical) {
                         // shadow_ray, include/light_impl.h:19-21: (light - point) through FP32
@@ -792,16 +804,6 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
                         sm.u2 = lt.u2;
                     }
                     mono_set_od<NEED_CROSS>(sm);
-                    if (valid) cnt.add(1);
-                    // A directional light behind the surface contributes exactly +0 whether or not it is shadowed:
-                    // surface_color multiplies by max(0.0f, (float) dot(n, light.p)) (include/light_impl.h:43), and the
-                    // colour it scales is finite.  Such lanes sit the shadow test out.  (COUNT builds test them anyway:
-                    // the reference-equivalent test count needs the index of the first blocker.)
-                    bool wanted = valid;
-                    if (!COUNT && !lt.spherical) {
-                        const float lam = (float) dot3(nrm, D3{lt.p[0], lt.p[1], lt.p[2]});
-                        wanted = valid && (0.0f < lam);
-                    }
                     const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC>(fa, S, gobj, sm, max_t, wanted, ball, lt, lane, cnt);
                     if (valid) {
                         // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)

@@ -375,6 +375,7 @@ extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config 
     // culling costs one bounding-volume decision per (object, light, 64-hit chunk); worth it from a handful
     // of bounded objects upwards
     fa.cull = (!(cfg.flags & RT_FLAG_NOCULL) && n_cullable >= 4) ? 1u : 0u;
+    fa.all_cullable = (fa.cull && n_cullable == sd->n_objects) ? 1u : 0u;
 
     // per-class tables behind the object array (rt_scene_dev.h)
     std::vector<UsEntry> t_us;

@@ -103,6 +103,7 @@ struct FrameArgs {
     uint32_t n_tiles;                           // tiles of this rank's rows (tiles_x * tiles_y)
     uint32_t rgba8;                             // 1: store iround(c*255) RGBA8 instead of RGBA32F
     uint32_t has_mirror;                        // some object has reflection_ratio > EPS
+    uint32_t all_cullable;                      // every object is a unit sphere with a finite bounding radius
 };
 
 #define RT_TILE 16        // a workgroup renders a 16 x 16 pixel tile

@@ -76,6 +76,9 @@ constexpr uint32_t WG = 256; // threads per workgroup = pixels per tile
 #ifndef RT_WF_OCC_NOMIRROR
 #define RT_WF_OCC_NOMIRROR 4
 #endif
+#ifndef RT_WF_OCC_SPHERES
+#define RT_WF_OCC_SPHERES 5 // mirror-free sphere / plane scenes: 94 VGPRs, no scratch
+#endif
 #ifndef RT_WF_CAMTAB
 #define RT_WF_CAMTAB 1
 #endif
@@ -607,7 +610,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
 // round loop is known to run once and the bounce state (ray direction, blend ratio, depth) is dead during the shadow
 // phase -- which is what lets the mirror-free instantiation fit 128 VGPRs (4 waves per SIMD).
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR>
-__global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_WF_OCC : RT_WF_OCC_NOMIRROR))) void wavefront_tile_kernel(const FrameArgs fa, const unsigned char *__restrict__ gscene,
+__global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_WF_OCC : ((!HAS_MIRROR && !HAS_GQ) ? RT_WF_OCC_SPHERES : RT_WF_OCC_NOMIRROR)))) void wavefront_tile_kernel(const FrameArgs fa, const unsigned char *__restrict__ gscene,
                                                               const DevLight *__restrict__ glight, void *__restrict__ fb,
                                                               unsigned long long *__restrict__ counters,
                                                               const double *__restrict__ camx, const double *__restrict__ camy)
@@ -662,6 +665,58 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
         // lanes outside the image trace a clamped pixel (keeps the wave's primary cone tight); their result is dropped
         const uint32_t xc = x < fa.width ? x : fa.width - 1, lrc = lr < fa.local_rows ? lr : fa.local_rows - 1;
         const uint32_t y = global_row(fa, lrc);
+
+        // ---- tile-level early-out ----
+        // When every object is a cullable sphere, ONE wave first tests the cone of the whole 16x16 tile (axis = the
+        // tile's centre pixel, half-angle from its four corner pixels: the same argument as primary_cone_mask) against
+        // all spheres.  83 % of the tiles of config 2 end here: nothing can be hit, the other three waves never form a
+        // ray, and the tile is just the background colour.
+        if (fa.all_cullable) { // launch-uniform
+            if (wave == 0) {
+                const uint32_t tx0 = tile_x * RT_TILE, ty0 = tile_y * RT_TILE;
+                uint32_t sx = tx0 + ((lane == 1 || lane == 3) ? RT_TILE - 1 : (lane >= 4 ? RT_TILE / 2 : 0));
+                uint32_t sy = ty0 + ((lane == 2 || lane == 3) ? RT_TILE - 1 : (lane >= 4 ? RT_TILE / 2 : 0));
+                sx = sx < fa.width ? sx : fa.width - 1;
+                sy = sy < fa.local_rows ? sy : fa.local_rows - 1;
+                const D3 sd = primary_dir_tab(fa, camx[sx], camy[global_row(fa, sy)]);
+                const D3 axis{readlane_d(sd.x, 4), readlane_d(sd.y, 4), readlane_d(sd.z, 4)};
+                const double ca = dot3(axis, sd);
+                const double c0 = readlane_d(ca, 0), c1 = readlane_d(ca, 1), c2 = readlane_d(ca, 2), c3 = readlane_d(ca, 3);
+                const double m01 = c0 < c1 ? c0 : c1, m23 = c2 < c3 ? c2 : c3;
+                const double cos_t = m01 < m23 ? m01 : m23;
+                const D3 org{fa.origin[0], fa.origin[1], fa.origin[2]};
+                unsigned long long any = 0;
+                for (uint32_t base = 0; base < fa.n_us; base += 64) {
+                    const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
+                    any |= primary_cone_mask(G.us, base, end, org, axis, cos_t, lane);
+                    if (lane == 0) cnt.add(7, end - base);
+                }
+                if (lane == 0) s_live[0] = any != 0ull ? 1u : 0u;
+            }
+            lds_barrier();
+            if (s_live[0] == 0) { // workgroup-uniform: the tile is pure background (src/update-cpu.cpp:93-95)
+                if (inside) {
+                    cnt.add(0);
+                    cnt.add(3, fa.n_obj);
+                    const size_t pix = (size_t) lr * fa.width + x;
+                    if (fa.rgba8) {
+                        uchar4 px;
+                        px.x = (unsigned char) (int) (bg.x * 255.0f + 0.5f);
+                        px.y = (unsigned char) (int) (bg.y * 255.0f + 0.5f);
+                        px.z = (unsigned char) (int) (bg.z * 255.0f + 0.5f);
+                        px.w = 255;
+                        reinterpret_cast<uchar4 *>(fb)[pix] = px;
+                    } else {
+                        reinterpret_cast<float4 *>(fb)[pix] = make_float4(bg.x, bg.y, bg.z, 1.0f);
+                    }
+                }
+                RT_STAMP(1);
+                RT_STAMP_FLUSH(counters, lane);
+                cnt.flush(counters);
+                return;
+            }
+            lds_barrier(); // s_live[0] is reused by the round loop
+        }
 
         F3 res = bg;
         D3 o{fa.origin[0], fa.origin[1], fa.origin[2]};

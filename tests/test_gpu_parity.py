@@ -363,3 +363,46 @@ def test_fly_through_sequence(pkg, oracle):
         r.update(cam)
         assert np.array_equal(r.download()[..., :3], osc.render(cam=cam, nthreads=8)), i
     r.cleanup_update()
+
+
+def mixed_scene(pkg, seed, w=128, h=96):
+    """Random mix of every degree <= 2 class: spheres, ellipsoids / hyperboloids / paraboloids with cross terms, planes;
+    directional and point lights; some mirrors."""
+    rng = np.random.default_rng(1000 + seed)
+    s = pkg.Scene.new(w, h, float(rng.uniform(35, 75)), int(rng.integers(0, 4)), rng.uniform(0, 1, 3))
+    for i in range(int(rng.integers(2, 14))):
+        kind = rng.integers(0, 4)
+        refl = float(rng.uniform(0.1, 0.9)) if rng.random() < 0.3 else 0.0
+        col = rng.uniform(0, 1, 3)
+        if kind <= 1:
+            s.add_object(pkg.surface_make("sphere", rng.uniform([-10, -6, 5], [10, 8, 35]), [float(rng.uniform(0.3, 3.0))]), col, refl)
+        elif kind == 2:
+            q = np.zeros(20)
+            q[10:13] = rng.uniform(-1.5, 2.0, 3)
+            if rng.random() < 0.5:
+                q[13:16] = rng.uniform(-0.5, 0.5, 3)
+            c = rng.uniform([-6, -4, 8], [6, 4, 25])
+            q[16:19] = -2.0 * q[10:13] * c
+            q[19] = float(np.dot(q[10:13], c * c) - rng.uniform(0.5, 6.0))
+            s.add_object(q, col, refl)
+        else:
+            n = rng.normal(size=3)
+            s.add_object(pkg.surface_make("plane", rng.uniform([-5, -8, 0], [5, -3, 30]), n / np.linalg.norm(n) + np.array([0, 1.5, 0])), col, refl)
+    for i in range(int(rng.integers(1, 6))):
+        if rng.random() < 0.5:
+            s.add_light("directional", rng.normal(size=3) + np.array([0, -1.2, 0]), rng.uniform(0, 1, 3), float(rng.uniform(0.3, 1.5)))
+        else:
+            s.add_light("spherical", rng.uniform([-12, -2, -5], [12, 15, 35]), rng.uniform(0, 1, 3), float(rng.uniform(100, 900)))
+    return s
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_mixed_class_scenes_bit_identical(pkg, oracle, seed):
+    """Every kernel instantiation for degree <= 2 (with / without general quadrics, with / without mirrors) against the
+    simple kernel and the oracle on random mixed scenes -- bit for bit."""
+    sc = mixed_scene(pkg, seed)
+    cam = pkg.camera_matrix(pos=(0.3 * (seed % 5) - 0.6, 0.2 * (seed % 3), -1.0 * (seed % 4)), yaw_deg=90.0 + (seed % 7) - 3, pitch_deg=(seed % 5) - 2.0)
+    a = render_desc(pkg, sc, cam)
+    assert np.array_equal(a, render_desc(pkg, sc, cam, flags=pkg.RT_FLAG_SIMPLE)), "wavefront vs simple"
+    want = oracle_from(pkg, oracle, sc).render(cam=cam, nthreads=8)
+    assert np.array_equal(a[..., :3], want)

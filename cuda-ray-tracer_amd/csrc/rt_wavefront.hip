@@ -278,18 +278,15 @@ __device__ __forceinline__ double wave_max(double v) RT_WAVE_REDUCE((t > v ? t :
 // centre from the cone's generator line (never larger than its distance to the cone), so the sphere is skipped
 // only when that exceeds r plus a margin (1e-6 relative + the cancellation error of the reference's own t0 for
 // huge coordinates).  Squared form, no sqrt / division.
-__device__ __forceinline__ unsigned long long primary_cone_mask(const UsEntry *us, uint32_t base, uint32_t end, const D3 &org,
-                                                                const D3 &axis, double cos_t, uint32_t lane)
+__device__ __forceinline__ bool sphere_in_cone(double kx, double ky, double kz, double r, double inv_r, const D3 &org, const D3 &axis,
+                                               double cos_t)
 {
-    bool rel = false;
-    const uint32_t j = base + lane;
-    if (j < end) {
-        const UsEntry e = us[j];
-        const double r = e.r;
+    bool rel;
+    {
         if (!(r < INFINITY)) {
             rel = true;
         } else {
-            const double ccx = -0.5 * e.kx, ccy = -0.5 * e.ky, ccz = -0.5 * e.kz;
+            const double ccx = -0.5 * kx, ccy = -0.5 * ky, ccz = -0.5 * kz;
             const double vx = ccx - org.x, vy = ccy - org.y, vz = ccz - org.z;
             const double vv = vx * vx + vy * vy + vz * vz;
             const double h = vx * axis.x + vy * axis.y + vz * axis.z;
@@ -301,10 +298,22 @@ __device__ __forceinline__ unsigned long long primary_cone_mask(const UsEntry *u
             double sin2 = 1.0 - c * c;
             sin2 = sin2 > 0.0 ? sin2 : 0.0;
             const double sn = sqrt(sin2);
-            const double lim = r + 1e-6 * (v1 + r + 1.0) + 1e-12 * (s2 + 1.0) * e.inv_r;
+            const double lim = r + 1e-6 * (v1 + r + 1.0) + 1e-12 * (s2 + 1.0) * inv_r;
             const double rhs = lim + h * sn; // need rho * c <= rhs
             rel = !(rhs < 0.0) && !(rho2 * c * c > rhs * rhs);
         }
+    }
+    return rel;
+}
+
+__device__ __forceinline__ unsigned long long primary_cone_mask(const UsEntry *us, uint32_t base, uint32_t end, const D3 &org,
+                                                                const D3 &axis, double cos_t, uint32_t lane)
+{
+    bool rel = false;
+    const uint32_t j = base + lane;
+    if (j < end) {
+        const UsEntry e = us[j];
+        rel = sphere_in_cone(e.kx, e.ky, e.kz, e.r, e.inv_r, org, axis, cos_t);
     }
     return __ballot(rel);
 }
@@ -673,20 +682,29 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
         // ray, and the tile is just the background colour.
         if (fa.all_cullable) { // launch-uniform
             if (wave == 0) {
+                // this lane's sphere (first group of 64) is requested first, so that the read's latency overlaps the
+                // direction arithmetic; the directions use the in-kernel divisions of primary_dir (same IEEE operations
+                // as the camera tables, hence the same values) instead of two more dependent global reads
+                double pkx = 0.0, pky = 0.0, pkz = 0.0, pr = 0.0, pinv = 0.0;
+                if (lane < fa.n_us) {
+                    const UsEntry *pe = &G.us[lane];
+                    pkx = pe->kx; pky = pe->ky; pkz = pe->kz; pr = pe->r; pinv = pe->inv_r;
+                }
                 const uint32_t tx0 = tile_x * RT_TILE, ty0 = tile_y * RT_TILE;
                 uint32_t sx = tx0 + ((lane == 1 || lane == 3) ? RT_TILE - 1 : (lane >= 4 ? RT_TILE / 2 : 0));
                 uint32_t sy = ty0 + ((lane == 2 || lane == 3) ? RT_TILE - 1 : (lane >= 4 ? RT_TILE / 2 : 0));
                 sx = sx < fa.width ? sx : fa.width - 1;
                 sy = sy < fa.local_rows ? sy : fa.local_rows - 1;
-                const D3 sd = primary_dir_tab(fa, camx[sx], camy[global_row(fa, sy)]);
+                const D3 sd = primary_dir(fa, (int) sx, (int) global_row(fa, sy));
                 const D3 axis{readlane_d(sd.x, 4), readlane_d(sd.y, 4), readlane_d(sd.z, 4)};
                 const double ca = dot3(axis, sd);
                 const double c0 = readlane_d(ca, 0), c1 = readlane_d(ca, 1), c2 = readlane_d(ca, 2), c3 = readlane_d(ca, 3);
                 const double m01 = c0 < c1 ? c0 : c1, m23 = c2 < c3 ? c2 : c3;
                 const double cos_t = m01 < m23 ? m01 : m23;
                 const D3 org{fa.origin[0], fa.origin[1], fa.origin[2]};
-                unsigned long long any = 0;
-                for (uint32_t base = 0; base < fa.n_us; base += 64) {
+                unsigned long long any = __ballot(lane < fa.n_us && sphere_in_cone(pkx, pky, pkz, pr, pinv, org, axis, cos_t));
+                if (lane == 0) cnt.add(7, fa.n_us < 64 ? fa.n_us : 64);
+                for (uint32_t base = 64; base < fa.n_us; base += 64) {
                     const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
                     any |= primary_cone_mask(G.us, base, end, org, axis, cos_t, lane);
                     if (lane == 0) cnt.add(7, end - base);

@@ -286,7 +286,20 @@ static uint32_t rows_of_rank(uint32_t height, uint32_t band, uint32_t world, uin
     return rows;
 }
 
+static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *cfg_in);
+
 extern "C" int rt_create(rt_ctx **out, const rt_scene_desc *sd, const rt_config *cfg_in)
+{
+    try { // host-side packing allocates; nothing may propagate through the C ABI
+        return create_impl(out, sd, cfg_in);
+    } catch (const std::bad_alloc &) {
+        return fail(RT_ERR_NOMEM, "rt_create: out of host memory");
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID, "rt_create: %s", e.what());
+    }
+}
+
+static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *cfg_in)
 {
     if (!out || !sd) return fail(RT_ERR_INVALID, "rt_create: null argument");
     *out = nullptr;

@@ -283,7 +283,10 @@ __device__ __forceinline__ bool sphere_in_cone(double kx, double ky, double kz, 
 {
     bool rel;
     {
-        if (!(r < INFINITY)) {
+        // The squared comparison below (and the corner-pixel bound on the half-angle) needs a cone narrower than a
+        // half-space.  A 16-pixel block only gets that wide with absurd aspect ratios (a 106 x 2 image at 86 degrees:
+        // found by tests/tools/fuzz_parity.py), but then nothing is culled.
+        if (!(r < INFINITY) || !(cos_t > 0.2)) {
             rel = true;
         } else {
             const double ccx = -0.5 * kx, ccy = -0.5 * ky, ccz = -0.5 * kz;

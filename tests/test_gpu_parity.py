@@ -434,3 +434,22 @@ def test_random_cubic_scenes_within_tolerance(pkg, oracle, seed):
     want = oracle_from(pkg, oracle, s).render(cam=cam, nthreads=8)
     c = compare(a[..., :3], want)
     assert c["n_bad_pixels"] <= max(3, int(0.002 * w * h)), c
+
+
+@pytest.mark.parametrize("seed", [158, 534] + list(range(2000, 2040)))
+def test_fuzz_regressions_and_sample(pkg, oracle, seed):
+    """tests/tools/fuzz_parity.py scenes: odd image sizes (down to 1 pixel), scene scales 0.1 .. 100, huge / tiny /
+    imaginary spheres, random quadrics, planes, mirrors, both light kinds, random cameras.  Seeds 158 and 534 are the
+    two scenes (106x2 and 71x3 pixels, cones wider than a half-space) on which the fuzzer caught the primary cone
+    culling before it was guarded."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    s, cam = fz.scene(seed)
+    a = render_desc(pkg, s, cam)
+    assert np.array_equal(a, render_desc(pkg, s, cam, flags=pkg.RT_FLAG_NOCULL))
+    assert np.array_equal(a, render_desc(pkg, s, cam, flags=pkg.RT_FLAG_SIMPLE))
+    assert np.array_equal(a[..., :3], oracle_from(pkg, oracle, s).render(cam=cam, nthreads=4), equal_nan=True)

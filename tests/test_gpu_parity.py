@@ -453,3 +453,23 @@ def test_fuzz_regressions_and_sample(pkg, oracle, seed):
     assert np.array_equal(a, render_desc(pkg, s, cam, flags=pkg.RT_FLAG_NOCULL))
     assert np.array_equal(a, render_desc(pkg, s, cam, flags=pkg.RT_FLAG_SIMPLE))
     assert np.array_equal(a[..., :3], oracle_from(pkg, oracle, s).render(cam=cam, nthreads=4), equal_nan=True)
+
+
+@pytest.mark.parametrize("h,band,world", [(37, 1, 2), (50, 3, 4), (64, 5, 3), (129, 16, 8), (100, 33, 2), (16, 8, 5), (7, 2, 6)])
+def test_row_band_ownership_variants(pkg, h, band, world):
+    """Any band height / rank count (bands that do not divide the tile height make a wave's four rows non-contiguous in
+    the image): every rank's local rows equal the corresponding rows of the single-context frame."""
+    w = 150
+    sc = random_scene(pkg, 99, 14, 5, w=w, h=h, mirrors=True)
+    full = render_desc(pkg, sc)
+    seen = np.zeros(h, dtype=bool)
+    for r in range(world):
+        ren = pkg.Renderer(sc, device=0, rank=r, world=world, band_rows=band)
+        rows = ren.row_map()
+        assert np.array_equal(rows, pkg.band_rows_of_rank(h, band, world, r))
+        ren.update()
+        if len(rows):
+            assert np.array_equal(ren.download(), full[rows]), (r, rows[:4])
+            seen[rows] = True
+        ren.cleanup_update()
+    assert seen.all()

@@ -102,6 +102,8 @@ struct rt_ctx {
     uint64_t *d_stamps = nullptr;
     double *d_camx = nullptr, *d_camy = nullptr; // per-column / per-row camera-plane coordinates
     size_t n_stamp_rows = 0;
+    uint32_t frame = 0; // renders so far: selects the launch-order generation (FrameArgs::order_state)
+    uint32_t *h_listed = nullptr; // host-mapped word the kernel writes (FrameArgs::ord_host)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -510,6 +512,25 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
             hip_ok(hipMalloc((void **) &ctx->d_camy, sizeof(double) * sd->height), "hipMalloc(camy)") &&
             hip_ok(hipMemcpy(ctx->d_camx, cx.data(), sizeof(double) * sd->width, hipMemcpyHostToDevice), "hipMemcpy(camx)") &&
             hip_ok(hipMemcpy(ctx->d_camy, cy.data(), sizeof(double) * sd->height, hipMemcpyHostToDevice), "hipMemcpy(camy)");
+        if (rc == RT_OK && !(cfg.flags & (RT_FLAG_SIMPLE | RT_FLAG_STATIC_ORDER)) && fa.n_tiles > 0) {
+            // launch-order feedback: three generations, all empty (first frame = index order)
+            fa.ord_stride = (RT_ORD_HDR + 5u * fa.n_tiles + 15u) & ~15u;
+            const size_t bytes = sizeof(uint32_t) * 3u * fa.ord_stride;
+            hip_ok(hipMalloc((void **) &fa.order_state, bytes), "hipMalloc(order)") && hip_ok(hipMemset(fa.order_state, 0, bytes), "hipMemset(order)");
+            // the kernel reports the number of listed tiles through one host-mapped word; without it (allocation
+            // refused) every launch simply carries n_tiles list slots
+            if (rc == RT_OK && hipHostMalloc((void **) &ctx->h_listed, 64, hipHostMallocMapped) == hipSuccess) {
+                *ctx->h_listed = 0;
+                if (hipHostGetDevicePointer((void **) &fa.ord_host, ctx->h_listed, 0) != hipSuccess) {
+                    (void) hipHostFree(ctx->h_listed);
+                    ctx->h_listed = nullptr;
+                    fa.ord_host = nullptr;
+                }
+            } else {
+                ctx->h_listed = nullptr;
+                (void) hipGetLastError();
+            }
+        }
         if (rc != RT_OK) {
             std::string keep = g_last_error;
             rt_destroy(ctx);
@@ -519,7 +540,7 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
     }
     ctx->zero_counters = std::getenv("MI355RT_DEBUG_COUNTERS") != nullptr;
     if (ctx->zero_counters) { // room for the stamp rows of a diagnostic (STAMPS=1) build: one per wave
-        ctx->n_stamp_rows = (size_t) fa.n_tiles * 4; // one row per wave
+        ctx->n_stamp_rows = (size_t) fa.n_tiles * 8; // one row per wave of the (up to) 2 * n_tiles workgroups of a launch
         if (hipMalloc((void **) &ctx->d_stamps, ctx->n_stamp_rows * 12 * sizeof(uint64_t) + 8) != hipSuccess) ctx->d_stamps = nullptr;
         else (void) hipMemset(ctx->d_stamps, 0, ctx->n_stamp_rows * 12 * sizeof(uint64_t));
     }
@@ -548,6 +569,21 @@ extern "C" int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *
         const unsigned long long ptr = (unsigned long long) (uintptr_t) ctx->d_stamps;
         RT_HIP(hipMemcpyAsync(ctx->d_counters + 31, &ptr, sizeof(ptr), hipMemcpyHostToDevice, stream));
         RT_HIP(hipStreamSynchronize(stream));
+    }
+    if (fa.order_state) { // rotate the launch-order generations: read k, write k+1, clear k+2
+        fa.ord_read = ctx->frame % 3u;
+        fa.ord_write = (ctx->frame + 1u) % 3u;
+        fa.ord_zero = (ctx->frame + 2u) % 3u;
+        // list slots of this launch: what an earlier frame reported (the host runs ahead of the device, so the word is
+        // a few frames old) plus a quarter and 64; too few only means that the surplus tiles start in index order
+        uint32_t cap = fa.n_tiles;
+        if (ctx->h_listed) {
+            const uint32_t seen = *(volatile uint32_t *) ctx->h_listed;
+            const uint64_t want = (uint64_t) seen + seen / 4u + 64u;
+            if (want < cap) cap = (uint32_t) want;
+        }
+        fa.ord_cap = cap;
+        ctx->frame++;
     }
     if (ms) RT_HIP(hipEventRecord(ctx->ev0, stream));
     const bool fast = (ctx->cfg.flags & RT_FLAG_FAST) != 0;
@@ -663,6 +699,8 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     if (ctx->d_stamps) (void) hipFree(ctx->d_stamps);
     if (ctx->d_camx) (void) hipFree(ctx->d_camx);
     if (ctx->d_camy) (void) hipFree(ctx->d_camy);
+    if (ctx->fa.order_state) (void) hipFree(ctx->fa.order_state);
+    if (ctx->h_listed) (void) hipHostFree(ctx->h_listed);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     delete ctx;

@@ -65,6 +65,8 @@ typedef struct rt_scene_desc {
                                  workgroup wavefront kernel (rt_wavefront.hip); same results, kept for A/B runs */
 #define RT_FLAG_NOCULL 8u     /* wavefront kernel: test every object for every shadow ray (no bounding-volume
                                  culling); same results, kept for A/B runs and as a cross-check */
+#define RT_FLAG_STATIC_ORDER 16u /* wavefront kernel: start the tiles in index order every frame instead of starting
+                                 the tiles that had hits in the previous frame first; same results, for A/B runs */
 
 /* rt_config.format -- framebuffer pixel format */
 #define RT_FMT_RGBA32F 0u     /* 4 x float per pixel, alpha 1.0: the un-quantised colours the CPU back end

@@ -206,10 +206,17 @@ def random_scene(pkg, seed, n_spheres, n_lights, w=160, h=120, with_plane=True, 
 
 
 def render_desc(pkg, sc, cam=None, **kw):
+    """Three frames from one context: the first runs the tiles in index order, the later ones in the launch order fed
+    back by the frame before (rt_wavefront.hip, "launch order from the previous frame"); the image must not notice."""
     r = pkg.Renderer(sc, device=0, **kw)
+    r.update(cam)
+    first = r.download().copy()
+    r.update(cam)
+    second = r.download().copy()
     r.update(cam)
     img = r.download()
     r.cleanup_update()
+    assert np.array_equal(first, second) and np.array_equal(first, img), "frame changed with the launch order"
     return img
 
 
@@ -473,3 +480,30 @@ def test_row_band_ownership_variants(pkg, h, band, world):
             seen[rows] = True
         ren.cleanup_update()
     assert seen.all()
+
+
+def test_launch_order_feedback_survives_camera_cuts(pkg, oracle):
+    """The launch order comes from the previous frame and the number of list slots from an even older one: cut between
+    an empty view, a full view and a partial one so that the lists are stale, too short (truncated) and too long in
+    turn.  Every frame equals the one an index-order context renders, and the first full one equals the oracle."""
+    sc = random_scene(pkg, 4242, 40, 6, w=640, h=360, with_plane=False)
+    r = pkg.Renderer(sc, device=0)
+    ref = pkg.Renderer(sc, device=0, flags=pkg.RT_FLAG_STATIC_ORDER)
+    away = pkg.camera_matrix((0.0, 0.0, 0.0), -90.0, 0.0)
+    front = pkg.camera_matrix((0.0, 0.0, 0.0), 90.0, 0.0)
+    side = pkg.camera_matrix((14.0, 2.0, 20.0), 160.0, -5.0)
+    seq = [away, away, front, front, front, front, side, front, away, side, side, front]
+    seen = {}
+    for i, cam in enumerate(seq):
+        r.update(cam)
+        got = r.download().copy()
+        key = cam.tobytes()
+        if key not in seen:
+            ref.update(cam)
+            seen[key] = ref.download().copy()
+        assert np.array_equal(got, seen[key]), f"frame {i}"
+    want = oracle_from(pkg, oracle, sc).render(cam=front, nthreads=8)
+    assert np.array_equal(seen[front.tobytes()][..., :3], want)
+    bg = np.asarray(sc.arrays()["bg_color"], dtype=np.float32)
+    assert np.all(seen[away.tobytes()][..., :3] == bg)          # the cuts really go through an empty frame
+    assert np.any(seen[front.tobytes()][..., :3] != bg)

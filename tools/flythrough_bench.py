@@ -16,7 +16,7 @@ W, H = 1920, 1080
 sc = pkg.Scene.load_from_file(os.path.join(ROOT, "scenes", "20spheres.yml")).set_size(W, H)
 r = pkg.Renderer(sc, device=0)
 rc = pkg.Renderer(sc, device=0, flags=pkg.RT_FLAG_COUNT)
-print(f"{'frame':>5} {'pos':>24} {'yaw':>6} {'pitch':>6} {'us':>8} {'hits':>8} {'rays':>9} {'Mrays/s':>9}")
+print(f"{'frame':>5} {'pos':>24} {'yaw':>6} {'pitch':>6} {'us':>8} {'hits':>8} {'rays':>9} {'Mrays/s':>9} {'exec':>9} {'solves':>8} {'culls':>8}")
 ts = []
 for i in range(24):
     a = 2.0 * np.pi * i / 24
@@ -29,6 +29,6 @@ for i in range(24):
     rc.update(cam)
     c = rc.counters()
     ts.append(t)
-    print(f"{i:5d} ({pos[0]:7.2f},{pos[1]:6.2f},{pos[2]:7.2f}) {yaw:6.1f} {pitch:6.1f} {t*1e3:8.1f} {c['hits']:8d} {c['rays_total']:9d} {c['rays_total']/t/1e3:9.0f}")
+    print(f"{i:5d} ({pos[0]:7.2f},{pos[1]:6.2f},{pos[2]:7.2f}) {yaw:6.1f} {pitch:6.1f} {t*1e3:8.1f} {c['hits']:8d} {c['rays_total']:9d} {c['rays_total']/t/1e3:9.0f} {c['tests_executed']:9d} {c['solves']:8d} {c['cull_evals']:8d}")
 ts = np.array(ts)
 print(f"frame time over the orbit: min {ts.min()*1e3:.1f} us, median {np.median(ts)*1e3:.1f} us, max {ts.max()*1e3:.1f} us")

@@ -103,7 +103,8 @@ struct rt_ctx {
     double *d_camx = nullptr, *d_camy = nullptr; // per-column / per-row camera-plane coordinates
     size_t n_stamp_rows = 0;
     uint32_t frame = 0; // renders so far: selects the launch-order generation (FrameArgs::order_state)
-    uint32_t *h_listed = nullptr; // host-mapped word the kernel writes (FrameArgs::ord_host)
+    uint32_t *h_listed = nullptr; // host-mapped words the kernel writes (FrameArgs::ord_host)
+    bool ord_on = true;           // launch-order feedback in use (off while most tiles have hits)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -512,7 +513,7 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
             hip_ok(hipMalloc((void **) &ctx->d_camy, sizeof(double) * sd->height), "hipMalloc(camy)") &&
             hip_ok(hipMemcpy(ctx->d_camx, cx.data(), sizeof(double) * sd->width, hipMemcpyHostToDevice), "hipMemcpy(camx)") &&
             hip_ok(hipMemcpy(ctx->d_camy, cy.data(), sizeof(double) * sd->height, hipMemcpyHostToDevice), "hipMemcpy(camy)");
-        if (rc == RT_OK && !(cfg.flags & (RT_FLAG_SIMPLE | RT_FLAG_STATIC_ORDER)) && fa.n_tiles > 0) {
+        if (rc == RT_OK && !(cfg.flags & (RT_FLAG_SIMPLE | RT_FLAG_STATIC_ORDER)) && fa.n_tiles > 0 && fa.n_tiles <= RT_ORD_MAX_TILES) {
             // launch-order feedback: three generations, all empty (first frame = index order)
             fa.ord_stride = (RT_ORD_HDR + 5u * fa.n_tiles + 15u) & ~15u;
             const size_t bytes = sizeof(uint32_t) * 3u * fa.ord_stride;
@@ -520,7 +521,8 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
             // the kernel reports the number of listed tiles through one host-mapped word; without it (allocation
             // refused) every launch simply carries n_tiles list slots
             if (rc == RT_OK && hipHostMalloc((void **) &ctx->h_listed, 64, hipHostMallocMapped) == hipSuccess) {
-                *ctx->h_listed = 0;
+                ctx->h_listed[0] = 0;
+                ctx->h_listed[1] = 0;
                 if (hipHostGetDevicePointer((void **) &fa.ord_host, ctx->h_listed, 0) != hipSuccess) {
                     (void) hipHostFree(ctx->h_listed);
                     ctx->h_listed = nullptr;
@@ -574,15 +576,19 @@ extern "C" int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *
         fa.ord_read = ctx->frame % 3u;
         fa.ord_write = (ctx->frame + 1u) % 3u;
         fa.ord_zero = (ctx->frame + 2u) % 3u;
-        // list slots of this launch: what an earlier frame reported (the host runs ahead of the device, so the word is
-        // a few frames old) plus a quarter and 64; too few only means that the surplus tiles start in index order
+        // list slots of this launch: what an earlier frame reported (the host runs ahead of the device, so the words
+        // are a few frames old) plus a quarter and 64; too few only means that the surplus tiles start in index order.
+        // The ordering is switched off while the census says that >= 25 % of the tiles have hits (back on below 20 %).
         uint32_t cap = fa.n_tiles;
         if (ctx->h_listed) {
-            const uint32_t seen = *(volatile uint32_t *) ctx->h_listed;
+            const uint32_t seen = ((volatile uint32_t *) ctx->h_listed)[0], census = ((volatile uint32_t *) ctx->h_listed)[1];
             const uint64_t want = (uint64_t) seen + seen / 4u + 64u;
             if (want < cap) cap = (uint32_t) want;
+            const uint64_t with_hits = (uint64_t) census * 16u;
+            if (ctx->ord_on ? with_hits * 4u >= fa.n_tiles : with_hits * 5u < fa.n_tiles) ctx->ord_on = !ctx->ord_on;
         }
         fa.ord_cap = cap;
+        fa.ord_on = ctx->ord_on ? 1u : 0u;
         ctx->frame++;
     }
     if (ms) RT_HIP(hipEventRecord(ctx->ev0, stream));

@@ -105,16 +105,18 @@ struct FrameArgs {
     uint32_t has_mirror;                        // some object has reflection_ratio > EPS
     uint32_t all_cullable;                      // every object is a unit sphere with a finite bounding radius
     // Launch-order feedback (wavefront kernel): three generations, ord_stride words apart, of
-    //   { count[4] (classes 4,3,2,1), pad[12], word[n_tiles], list[4][n_tiles] }     (uint32)
+    //   { count[4] (classes 4,3,2,1), census, pad[11], word[n_tiles], list[4][n_tiles] }     (uint32)
     // word[t] = (position in its class list << 3) | class, 0 = no hits.  Frame k reads what frame k-1 wrote, writes its
     // own generation and clears the counters frame k+1 will append to.  NULL = tiles run in index order.
     uint32_t *order_state;
-    uint32_t *ord_host;   // host-mapped word: the kernel reports how many tiles were listed (sizes later launches)
+    uint32_t *ord_host;   // host-mapped {listed tiles, census} of the previous frame: sizes / switches later launches
     uint32_t ord_stride, ord_read, ord_write, ord_zero;
     uint32_t ord_cap;     // list slots in this launch (the grid is ord_cap + n_tiles workgroups)
+    uint32_t ord_on;      // 0: index order this frame, census only
 };
 
 #define RT_TILE 16        // a workgroup renders a 16 x 16 pixel tile
-#define RT_ORD_HDR 16      // words before class[] in one generation of FrameArgs::order_state
+#define RT_ORD_HDR 16      // words before word[] in one generation of FrameArgs::order_state
+#define RT_ORD_MAX_TILES 16384u // larger launches are many workgroups per slot deep: the order stops mattering
 
 #endif

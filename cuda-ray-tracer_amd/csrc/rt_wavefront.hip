@@ -74,15 +74,26 @@ constexpr uint32_t WG = 256; // threads per workgroup = pixels per tile
 #define RT_STAMP(i)
 #define RT_STAMP_FLUSH(c, lane)
 #endif
-#ifndef RT_WF_OCC
-#define RT_WF_OCC 3
+// Occupancy target (waves per SIMD) of each instantiation = the highest one at which NOTHING spills to scratch.
+// That is a correctness rule, not tuning: ROCm 7.2's compiler can place a VGPR spill at the top of a join block before
+// the `s_or_b64 exec` that re-enables the lanes of a divergent region, so the lanes that sat the region out read back
+// whatever the scratch slot held (tools/check_spills.py has the story and is run by `make`).  SGPR spills (to VGPR
+// lanes) are harmless.  RT_WF_OCC_DELTA (make OCCD=-1 ...) shifts every target for experiments.
+#ifndef RT_FAST
+#define RT_FAST 0
 #endif
-#ifndef RT_WF_OCC_NOMIRROR
-#define RT_WF_OCC_NOMIRROR 4
+#ifndef RT_WF_OCC_DELTA
+#define RT_WF_OCC_DELTA 0
 #endif
-#ifndef RT_WF_OCC_SPHERES
-#define RT_WF_OCC_SPHERES 5 // mirror-free sphere / plane scenes: 94 VGPRs, no scratch
-#endif
+template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR>
+constexpr int wf_occupancy()
+{
+    int occ = HAS_CUBIC ? 2 : (HAS_MIRROR ? 3 : (HAS_GQ ? 4 : 5)); // 94 / 127 / 168 / ~200 VGPRs (strict, no counters)
+    if (!HAS_CUBIC && (COUNT || RT_FAST)) occ -= 1; // counters / the FMA build's different schedule need a few registers more
+    if (!HAS_CUBIC && COUNT && RT_FAST && HAS_MIRROR) occ -= 1;
+    occ += RT_WF_OCC_DELTA;
+    return occ < 1 ? 1 : occ;
+}
 #ifndef RT_WF_CAMTAB
 #define RT_WF_CAMTAB 1
 #endif
@@ -626,7 +637,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
 // round loop is known to run once and the bounce state (ray direction, blend ratio, depth) is dead during the shadow
 // phase -- which is what lets the mirror-free instantiation fit 128 VGPRs (4 waves per SIMD).
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR>
-__global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_WF_OCC : ((!HAS_MIRROR && !HAS_GQ) ? RT_WF_OCC_SPHERES : RT_WF_OCC_NOMIRROR)))) void wavefront_tile_kernel(const FrameArgs fa, const unsigned char *__restrict__ gscene,
+__global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MIRROR>())) void wavefront_tile_kernel(const FrameArgs fa, const unsigned char *__restrict__ gscene,
                                                               const DevLight *__restrict__ glight, void *__restrict__ fb,
                                                               unsigned long long *__restrict__ counters,
                                                               const double *__restrict__ camx, const double *__restrict__ camy)
@@ -679,19 +690,40 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
     // lists (four cost classes, heaviest first; n_eff = the listed tiles that fit into ord_cap slots), the last
     // n_tiles slots are the tiles in index order, and the ones a list slot covers exit at once.  Every tile is
     // rendered exactly once whatever the lists and ord_cap say, so they change the time, never the image.
+    //
+    // This pays when few tiles have hits and the launch is only a few workgroups per slot deep (config 2: 15 % of 8160
+    // tiles, -7 %); otherwise it costs a dependent load at the start of every workgroup and one same-address device
+    // atomic per tile with hits (those sustain ~90 per microsecond): +5 % on a frame where every tile has hits.  So
+    // one tile in 16 takes part in a census, the host sees it through a mapped word and switches the ordering off
+    // (ord_on = 0: index order, nothing read or appended, census only) while >= 25 % of the tiles have hits.
     uint32_t *ord_wr = nullptr;
     uint32_t tile = blockIdx.x;
-    bool listed = false; // this tile had hits in the previous frame
-    if (fa.order_state) { // launch-uniform
+    bool listed = false;  // this tile had hits in the previous frame
+    bool listing = false; // this frame appends to the lists
+    bool covered = false; // index-order slot whose tile a list slot renders: leaves before its first side effect
+    if (fa.order_state && !fa.ord_on) { // launch-uniform: census only
+        ord_wr = fa.order_state + (size_t) fa.ord_write * fa.ord_stride;
+        if (blockIdx.x == 0 && tid == 0) {
+            const uint32_t *ord_rd = fa.order_state + (size_t) fa.ord_read * fa.ord_stride;
+            uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride;
+            *reinterpret_cast<uint4 *>(z) = make_uint4(0, 0, 0, 0);
+            z[4] = 0;
+            if (fa.ord_host) { fa.ord_host[0] = 0; fa.ord_host[1] = ord_rd[4]; }
+        }
+    }
+    if (fa.order_state && fa.ord_on) { // launch-uniform
         const uint32_t *ord_rd = fa.order_state + (size_t) fa.ord_read * fa.ord_stride;
         ord_wr = fa.order_state + (size_t) fa.ord_write * fa.ord_stride;
         const uint4 cn = *reinterpret_cast<const uint4 *>(ord_rd); // listed tiles of class 4, 3, 2, 1
+        const uint32_t census = ord_rd[4];                          // tiles with hits in the previous frame, 1 in 16 counted
+        listing = census * 64u < fa.n_tiles;                        // the host's switch lags a few frames: same rule here
         const uint32_t e1 = cn.x, e2 = e1 + cn.y, e3 = e2 + cn.z, n_listed = e3 + cn.w;
         const uint32_t n_eff = n_listed < fa.ord_cap ? n_listed : fa.ord_cap;
         if (blockIdx.x == 0 && tid == 0) {
             uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride; // the generation the NEXT frame appends to
             *reinterpret_cast<uint4 *>(z) = make_uint4(0, 0, 0, 0);
-            if (fa.ord_host) *fa.ord_host = n_listed; // host-mapped: sizes the list part of a later launch
+            z[4] = 0;
+            if (fa.ord_host) { fa.ord_host[0] = n_listed; fa.ord_host[1] = census; } // host-mapped: sizes / switches later launches
         }
         if (blockIdx.x < fa.ord_cap) {
             if (blockIdx.x >= n_eff) return; // workgroup-uniform
@@ -706,7 +738,7 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
             if (w != 0) {
                 const uint32_t k = 4u - (w & 7u);
                 const uint32_t first = k == 0 ? 0u : (k == 1 ? e1 : (k == 2 ? e2 : e3));
-                if (first + (w >> 3) < n_eff) return; // a list slot renders it
+                covered = first + (w >> 3) < n_eff;
             }
         }
     }
@@ -755,6 +787,7 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
                 }
                 if (lane == 0) s_live[0] = any != 0ull ? 1u : 0u;
             }
+            if (covered) return; // workgroup-uniform
             lds_barrier();
             if (s_live[0] == 0) { // workgroup-uniform: the tile is pure background (src/update-cpu.cpp:93-95)
                 if (inside) {
@@ -772,7 +805,7 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
                         reinterpret_cast<float4 *>(fb)[pix] = make_float4(bg.x, bg.y, bg.z, 1.0f);
                     }
                 }
-                if (ord_wr && tid == 0) ord_wr[RT_ORD_HDR + tile] = 0;
+                if (ord_wr && fa.ord_on && tid == 0) ord_wr[RT_ORD_HDR + tile] = 0;
                 RT_STAMP(1);
                 RT_STAMP_FLUSH(counters, lane);
                 cnt.flush(counters);
@@ -788,6 +821,7 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
 #else
         D3 dir = primary_dir(fa, (int) xc, (int) y);
 #endif
+        if (covered) return; // workgroup-uniform
         bool live = inside; // this pixel still has a ray to trace
         bool first = true;
         uint32_t ord_cls = 0, ord_pos = 0; // thread 0: this tile's entry in the next frame's launch order
@@ -830,8 +864,11 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
             const uint32_t c0 = s_wcount[0], c1 = s_wcount[1], c2 = s_wcount[2], c3 = s_wcount[3];
             const uint32_t n_hits = c0 + c1 + c2 + c3;
             if (first && ord_wr && tid == 0 && n_hits) { // the next frame's launch order: round-0 hits in four cost classes
-                ord_cls = 1u + ((n_hits - 1u) >> 6); // 1..64 -> 1, ..., 193..256 -> 4
-                ord_pos = atomicAdd(&ord_wr[4u - ord_cls], 1u); // only needed at the very end: the round trip costs nothing
+                if (((tile * 0x9E3779B1u) >> 28) == 0u) atomicAdd(&ord_wr[4], 1u); // census, also while the ordering is off
+                if (listing) {
+                    ord_cls = 1u + ((n_hits - 1u) >> 6); // 1..64 -> 1, ..., 193..256 -> 4
+                    ord_pos = atomicAdd(&ord_wr[4u - ord_cls], 1u); // only needed at the very end: the round trip costs nothing
+                }
             }
             if (n_hits == 0) break; // workgroup-uniform: nothing left to shade or bounce (all lanes are dead by now)
             const uint32_t n_chunks = (n_hits + 63) >> 6;
@@ -1014,7 +1051,7 @@ __global__ __launch_bounds__(256, (HAS_CUBIC ? 2 : ((HAS_MIRROR && HAS_GQ) ? RT_
                 reinterpret_cast<float4 *>(fb)[pix] = make_float4(res.x, res.y, res.z, 1.0f);
             }
         }
-        if (ord_wr && tid == 0) {
+        if (ord_wr && fa.ord_on && tid == 0) {
             if (ord_cls) ord_wr[RT_ORD_HDR + (5u - ord_cls) * fa.n_tiles + ord_pos] = tile;
             ord_wr[RT_ORD_HDR + tile] = ord_cls ? ((ord_pos << 3) | ord_cls) : 0u;
         }
@@ -1044,7 +1081,7 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
 {
     using namespace RT_SYM(rtw);
     if (fa->n_tiles == 0) return hipSuccess;
-    const dim3 grid(fa->order_state ? fa->ord_cap + fa->n_tiles : fa->n_tiles), block(WG);
+    const dim3 grid((fa->order_state && fa->ord_on) ? fa->ord_cap + fa->n_tiles : fa->n_tiles), block(WG);
     const size_t lds = LdsLayout(fa->stage_bytes, fa->n_lights).total;
     const unsigned char *gs = reinterpret_cast<const unsigned char *>(gobj);
     const int sel = (count ? 8 : 0) | (fa->has_mirror ? 4 : 0) | (fa->n_gq ? 2 : 0) | (fa->n_cub ? 1 : 0);

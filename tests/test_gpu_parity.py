@@ -507,3 +507,16 @@ def test_launch_order_feedback_survives_camera_cuts(pkg, oracle):
     bg = np.asarray(sc.arrays()["bg_color"], dtype=np.float32)
     assert np.all(seen[away.tobytes()][..., :3] == bg)          # the cuts really go through an empty frame
     assert np.any(seen[front.tobytes()][..., :3] != bg)
+
+
+@pytest.mark.parametrize("name,flags", [("quadratic", 1), ("reflection_test", 0), ("20spheres", 1), ("reflection_test", 3)])
+def test_first_kernel_of_a_fresh_process(pkg, name, flags):
+    """A frame must not depend on what earlier launches left in scratch memory (tools/check_spills.py): render in a
+    fresh process, where this kernel is the first GPU work at all, and compare with the simple kernel there."""
+    import os
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "first_in_process.py")
+    out = subprocess.run([sys.executable, tool, name, str(flags)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "OK", out.stdout

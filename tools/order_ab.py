@@ -47,3 +47,14 @@ for n in (240, 2400):
         r.update(pose(0, n))
         tot.append(sum(r.update(pose(i, n)) for i in range(n)) / n * 1e3)
     print(f"  mean frame: feedback {tot[0]:6.1f} us   index order {tot[1]:6.1f} us")
+
+print("start-up pose of the other BASELINE configs (median of 20 frames)")
+for name, w, h in (("quadratic", 640, 480), ("reflection_test", 1920, 1080), ("clebsch", 3840, 2160), ("20spheres", 7680, 4320)):
+    s2 = pkg.Scene.load_from_file(os.path.join(ROOT, "scenes", name + ".yml")).set_size(w, h)
+    ts = []
+    for fl in (0, pkg.RT_FLAG_STATIC_ORDER):
+        r = pkg.Renderer(s2, device=0, flags=fl)
+        r.update(None); r.update(None); r.update(None)
+        ts.append(float(np.median([r.update(None) for _ in range(20)])) * 1e3)
+        r.cleanup_update()
+    print(f"  {name:16s} {w}x{h}: feedback {ts[0]:7.1f} us   index order {ts[1]:7.1f} us")

@@ -88,7 +88,7 @@ constexpr uint32_t WG = 256; // threads per workgroup = pixels per tile
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR>
 constexpr int wf_occupancy()
 {
-    int occ = HAS_CUBIC ? 2 : (HAS_MIRROR ? 3 : (HAS_GQ ? 4 : 5)); // 94 / 127 / 168 / ~200 VGPRs (strict, no counters)
+    int occ = HAS_CUBIC ? 2 : (HAS_MIRROR ? (HAS_GQ ? 3 : 4) : (HAS_GQ ? 4 : 5)); // 94 / 127 / 128 / 168 / ~200 VGPRs (strict, no counters)
     if (!HAS_CUBIC && (COUNT || RT_FAST)) occ -= 1; // counters / the FMA build's different schedule need a few registers more
     if (!HAS_CUBIC && COUNT && RT_FAST && HAS_MIRROR) occ -= 1;
     occ += RT_WF_OCC_DELTA;
@@ -513,8 +513,8 @@ __host__ __device__ inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15
 
 // LDS carve-up (dynamic shared memory), shared by kernel and launcher.
 struct LdsLayout {
-    uint32_t scene, light, hp, hn, hdir, hidx, hpix, color, shadow, ball, misc, total, shadow_words;
-    __host__ __device__ LdsLayout(uint32_t scene_bytes, uint32_t n_lights)
+    uint32_t scene, light, hp, hn, hdir, park, hidx, hpix, color, shadow, ball, misc, total, shadow_words;
+    __host__ __device__ LdsLayout(uint32_t scene_bytes, uint32_t n_lights, bool has_mirror)
     {
         shadow_words = (n_lights + 31) / 32;
         if (shadow_words == 0) shadow_words = 1;
@@ -523,7 +523,8 @@ struct LdsLayout {
         light = off; off = align16(off + n_lights * (uint32_t) sizeof(DevLight));
         hp = off; off = align16(off + 3 * WG * 8);
         hn = off; off = align16(off + 3 * WG * 8);
-        hdir = off; off = align16(off + 3 * WG * 8);
+        hdir = off; off = align16(off + (has_mirror ? 3 * WG * 8 : 0)); // mirrors only: the pixel's incoming direction ...
+        park = off; off = align16(off + (has_mirror ? 5 * WG * 4 : 0)); // ... and its running colour / ratio / depth, parked across B and C
         hidx = off; off = align16(off + WG * 4);
         hpix = off; off = align16(off + WG * 4);
         color = off; off = align16(off + 3 * WG * 4);
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool NEED_CROSS = HAS_GQ || HAS_CUBIC;
-    const LdsLayout L(fa.stage_bytes, fa.n_lights);
+    const LdsLayout L(fa.stage_bytes, fa.n_lights, HAS_MIRROR);
     const DevObject *gobj = reinterpret_cast<const DevObject *>(gscene); // full object records: global memory only
     SceneLds S; // class tables + materials staged in LDS (only tiles with hits ever stage them); LDS offset = blob offset - off_us
     S.us = reinterpret_cast<const UsEntry *>(smem + L.scene);
@@ -666,6 +667,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     uint32_t *hidx = reinterpret_cast<uint32_t *>(smem + L.hidx); // object of hit h
     uint32_t *hpix = reinterpret_cast<uint32_t *>(smem + L.hpix); // owner lane (pixel) of hit h
     float *scolor = reinterpret_cast<float *>(smem + L.color);    // [3][WG] direct lighting of the pixel's hit this round
+    float *spark = reinterpret_cast<float *>(smem + L.park);      // [5][WG] mirrors: running colour, blend ratio, depth of the pixel
     uint32_t *sshadow = reinterpret_cast<uint32_t *>(smem + L.shadow); // [WG][shadow_words] bit l: light l is blocked
     Ball *sball = reinterpret_cast<Ball *>(smem + L.ball);
     uint32_t *s_wcount = reinterpret_cast<uint32_t *>(smem + L.misc); // [4] hits found by each wave this round
@@ -894,6 +896,11 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     hdir[tid] = dir.x; hdir[WG + tid] = dir.y; hdir[2 * WG + tid] = dir.z;
                 }
             }
+            if (HAS_MIRROR) { // so does the blend: running colour, ratio and depth wait in LDS while phases B and C run
+                spark[tid] = res.x; spark[WG + tid] = res.y; spark[2 * WG + tid] = res.z;
+                spark[3 * WG + tid] = cur_ratio;
+                reinterpret_cast<uint32_t *>(spark)[4 * WG + tid] = n_refl;
+            }
             if (tid < n_hits)
                 for (uint32_t w = 0; w < L.shadow_words; w++) sshadow[tid * L.shadow_words + w] = 0;
             lds_barrier();
@@ -1003,11 +1010,16 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             lds_barrier();
 
             // ---------------- phase D: blend, set up the bounce ----------------
+            if (HAS_MIRROR) {
+                res = F3{spark[tid], spark[WG + tid], spark[2 * WG + tid]};
+                cur_ratio = spark[3 * WG + tid];
+                n_refl = reinterpret_cast<const uint32_t *>(spark)[4 * WG + tid];
+            }
             if (hit) {
                 const F3 oc{scolor[tid], scolor[WG + tid], scolor[2 * WG + tid]};
                 if (first) res = oc;
                 else blend(res, cur_ratio, oc);
-                const float refl = HAS_MIRROR ? S.mat[best].refl : 0.0f;
+                const float refl = HAS_MIRROR ? S.mat[hidx[my_slot]].refl : 0.0f; // `best` is not kept across B / C
                 if (!HAS_MIRROR || !((double) refl > EPS)) {
                     live = false;
                 } else {
@@ -1038,8 +1050,13 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             if (!more) break;
         }
 
-        if (inside) {
-            const size_t pix = (size_t) lr * fa.width + x;
+        // the pixel's coordinates are formed again here (from an opaque copy of tid) instead of being kept in registers
+        // through all the rounds; one more lever that keeps the mirror instantiations free of scratch spills
+        uint32_t tid_ = tid;
+        if (HAS_MIRROR) asm volatile("" : "+v"(tid_));
+        const uint32_t sx_ = (tile % fa.tiles_x) * RT_TILE + (tid_ & 15), sy_ = (tile / fa.tiles_x) * RT_TILE + (tid_ >> 4);
+        if (sx_ < fa.width && sy_ < fa.local_rows) {
+            const size_t pix = (size_t) sy_ * fa.width + sx_;
             if (fa.rgba8) {
                 uchar4 px;
                 px.x = (unsigned char) (int) (res.x * 255.0f + 0.5f);
@@ -1065,9 +1082,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
 
 } // namespace RT_SYM(rtw)
 
-extern "C" size_t RT_SYM(rt_wavefront_lds_bytes)(uint32_t stage_bytes, uint32_t n_lights)
+extern "C" size_t RT_SYM(rt_wavefront_lds_bytes)(uint32_t stage_bytes, uint32_t n_lights, int has_mirror)
 {
-    return RT_SYM(rtw)::LdsLayout(stage_bytes, n_lights).total;
+    return RT_SYM(rtw)::LdsLayout(stage_bytes, n_lights, has_mirror != 0).total;
 }
 
 // One workgroup per 16x16 tile; the dispatcher hands tiles to CUs as they free up, which is the dynamic load
@@ -1082,7 +1099,7 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
     using namespace RT_SYM(rtw);
     if (fa->n_tiles == 0) return hipSuccess;
     const dim3 grid((fa->order_state && fa->ord_on) ? fa->ord_cap + fa->n_tiles : fa->n_tiles), block(WG);
-    const size_t lds = LdsLayout(fa->stage_bytes, fa->n_lights).total;
+    const size_t lds = LdsLayout(fa->stage_bytes, fa->n_lights, fa->has_mirror != 0).total;
     const unsigned char *gs = reinterpret_cast<const unsigned char *>(gobj);
     const int sel = (count ? 8 : 0) | (fa->has_mirror ? 4 : 0) | (fa->n_gq ? 2 : 0) | (fa->n_cub ? 1 : 0);
 #define RT_LAUNCH(C, M, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q, M>), grid, block, lds, stream, *fa, gs, glight, fb, counters, camx, camy)

@@ -106,7 +106,8 @@ struct FrameArgs {
     uint32_t all_cullable;                      // every object is a unit sphere with a finite bounding radius
     // Launch-order feedback (wavefront kernel): three generations, ord_stride words apart, of
     //   { count[4] (classes 4,3,2,1), census, pad[11], word[n_tiles], list[4][n_tiles] }     (uint32)
-    // word[t] = (position in its class list << 3) | class, 0 = no hits.  Frame k reads what frame k-1 wrote, writes its
+    // word[t] = (position in its class list << 3) | class, written only by tiles with hits (a stale word is harmless: the
+    // reader checks that the list entry it points at names tile t).  Frame k reads what frame k-1 wrote, writes its
     // own generation and clears the counters frame k+1 will append to.  NULL = tiles run in index order.
     uint32_t *order_state;
     uint32_t *ord_host;   // host-mapped {listed tiles, census} of the previous frame: sizes / switches later launches

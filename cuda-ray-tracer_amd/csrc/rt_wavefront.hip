@@ -698,6 +698,13 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     // atomic per tile with hits (those sustain ~90 per microsecond): +5 % on a frame where every tile has hits.  So
     // one tile in 16 takes part in a census, the host sees it through a mapped word and switches the ordering off
     // (ord_on = 0: index order, nothing read or appended, census only) while >= 25 % of the tiles have hits.
+    // tile-level early-out (below): lane j of wave 0 tests sphere j, whatever the tile -- so the entry is requested
+    // before the tile is even known and its latency overlaps with the order-state reads
+    double pkx = 0.0, pky = 0.0, pkz = 0.0, pr = 0.0, pinv = 0.0;
+    if (fa.all_cullable && wave == 0 && lane < fa.n_us) {
+        const UsEntry *pe = &G.us[lane];
+        pkx = pe->kx; pky = pe->ky; pkz = pe->kz; pr = pe->r; pinv = pe->inv_r;
+    }
     uint32_t *ord_wr = nullptr;
     uint32_t tile = blockIdx.x;
     bool listed = false;  // this tile had hits in the previous frame
@@ -714,12 +721,24 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         }
     }
     if (fa.order_state && fa.ord_on) { // launch-uniform
-        const uint32_t *ord_rd = fa.order_state + (size_t) fa.ord_read * fa.ord_stride;
+        // the generation being read was written by the previous launch and is not touched by this one: constant address
+        // space, so that the reads become scalar loads (through the generic pointer they are vector loads + readfirstlane)
+        typedef const __attribute__((address_space(4))) uint32_t *ConstWords;
+        ConstWords ord_rd = (ConstWords) (fa.order_state + (size_t) fa.ord_read * fa.ord_stride);
         ord_wr = fa.order_state + (size_t) fa.ord_write * fa.ord_stride;
-        const uint4 cn = *reinterpret_cast<const uint4 *>(ord_rd); // listed tiles of class 4, 3, 2, 1
+        const uint32_t cn_x = ord_rd[0], cn_y = ord_rd[1], cn_z = ord_rd[2], cn_w = ord_rd[3]; // listed tiles of class 4, 3, 2, 1
         const uint32_t census = ord_rd[4];                          // tiles with hits in the previous frame, 1 in 16 counted
+        // the per-tile word of an index-order slot is requested with them (for a list slot: tile 0's, unused)
+        const uint32_t idx_tile = blockIdx.x >= fa.ord_cap ? blockIdx.x - fa.ord_cap : 0u;
+        const uint32_t w = ord_rd[RT_ORD_HDR + idx_tile]; // (position in its class list << 3) | class, 0 = had no hits
+        // ask for the camera / frame part of the kernel arguments here, between issuing the order-state reads and using
+        // them: otherwise the compiler sinks those loads below the order decode and a workgroup starts with three
+        // dependent round trips (arguments, order state, arguments again)
+        asm volatile("" ::"s"(fa.cam[0]), "s"(fa.cam[2]), "s"(fa.cam[5]), "s"(fa.cam[6]), "s"(fa.cam[8]), "s"(fa.cam[10]), "s"(fa.origin[0]),
+                     "s"(fa.origin[2]), "s"(fa.aspect), "s"(fa.tan_half_fov), "s"(fa.width), "s"(fa.local_rows), "s"(fa.tiles_x), "s"(fa.n_us),
+                     "s"(fa.off_us), "s"(fa.band_rows), "s"(fa.all_cullable), "s"(gscene), "s"(w));
         listing = census * 64u < fa.n_tiles;                        // the host's switch lags a few frames: same rule here
-        const uint32_t e1 = cn.x, e2 = e1 + cn.y, e3 = e2 + cn.z, n_listed = e3 + cn.w;
+        const uint32_t e1 = cn_x, e2 = e1 + cn_y, e3 = e2 + cn_z, n_listed = e3 + cn_w;
         const uint32_t n_eff = n_listed < fa.ord_cap ? n_listed : fa.ord_cap;
         if (blockIdx.x == 0 && tid == 0) {
             uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride; // the generation the NEXT frame appends to
@@ -735,12 +754,15 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             tile = ord_rd[RT_ORD_HDR + (1u + k) * fa.n_tiles + (b - first)];
             listed = true;
         } else {
-            tile = blockIdx.x - fa.ord_cap;
-            const uint32_t w = ord_rd[RT_ORD_HDR + tile]; // (position in its class list << 3) | class, 0 = had no hits
-            if (w != 0) {
-                const uint32_t k = 4u - (w & 7u);
+            tile = idx_tile;
+            // A tile without hits writes nothing, so its word may be left over from an older frame of this generation:
+            // the word is only a hint where to look, and the tile counts as covered iff that list entry really names it.
+            const uint32_t cls = w & 7u, pos = w >> 3;
+            if (cls >= 1u && cls <= 4u && pos < fa.n_tiles) {
+                const uint32_t k = 4u - cls;
                 const uint32_t first = k == 0 ? 0u : (k == 1 ? e1 : (k == 2 ? e2 : e3));
-                covered = first + (w >> 3) < n_eff;
+                const uint32_t count = k == 0 ? cn_x : (k == 1 ? cn_y : (k == 2 ? cn_z : cn_w));
+                if (pos < count && first + pos < n_eff) covered = ord_rd[RT_ORD_HDR + (1u + k) * fa.n_tiles + pos] == tile;
             }
         }
     }
@@ -760,14 +782,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         // ray, and the tile is just the background colour.
         if (fa.all_cullable && !listed) { // launch-uniform x workgroup-uniform; a listed tile almost surely has hits again
             if (wave == 0) {
-                // this lane's sphere (first group of 64) is requested first, so that the read's latency overlaps the
-                // direction arithmetic; the directions use the in-kernel divisions of primary_dir (same IEEE operations
-                // as the camera tables, hence the same values) instead of two more dependent global reads
-                double pkx = 0.0, pky = 0.0, pkz = 0.0, pr = 0.0, pinv = 0.0;
-                if (lane < fa.n_us) {
-                    const UsEntry *pe = &G.us[lane];
-                    pkx = pe->kx; pky = pe->ky; pkz = pe->kz; pr = pe->r; pinv = pe->inv_r;
-                }
+                // this lane's sphere (first group of 64) was requested at the top of the kernel; the directions use the
+                // in-kernel divisions of primary_dir (same IEEE operations as the camera tables, hence the same values)
+                // instead of two more dependent global reads
                 const uint32_t tx0 = tile_x * RT_TILE, ty0 = tile_y * RT_TILE;
                 uint32_t sx = tx0 + ((lane == 1 || lane == 3) ? RT_TILE - 1 : (lane >= 4 ? RT_TILE / 2 : 0));
                 uint32_t sy = ty0 + ((lane == 2 || lane == 3) ? RT_TILE - 1 : (lane >= 4 ? RT_TILE / 2 : 0));
@@ -807,7 +824,6 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                         reinterpret_cast<float4 *>(fb)[pix] = make_float4(bg.x, bg.y, bg.z, 1.0f);
                     }
                 }
-                if (ord_wr && fa.ord_on && tid == 0) ord_wr[RT_ORD_HDR + tile] = 0;
                 RT_STAMP(1);
                 RT_STAMP_FLUSH(counters, lane);
                 cnt.flush(counters);
@@ -1068,9 +1084,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 reinterpret_cast<float4 *>(fb)[pix] = make_float4(res.x, res.y, res.z, 1.0f);
             }
         }
-        if (ord_wr && fa.ord_on && tid == 0) {
-            if (ord_cls) ord_wr[RT_ORD_HDR + (5u - ord_cls) * fa.n_tiles + ord_pos] = tile;
-            ord_wr[RT_ORD_HDR + tile] = ord_cls ? ((ord_pos << 3) | ord_cls) : 0u;
+        if (ord_cls) { // thread 0 of a tile with hits, ordering on
+            ord_wr[RT_ORD_HDR + (5u - ord_cls) * fa.n_tiles + ord_pos] = tile;
+            ord_wr[RT_ORD_HDR + tile] = (ord_pos << 3) | ord_cls;
         }
         RT_STAMP(10);
     }

@@ -520,3 +520,40 @@ def test_first_kernel_of_a_fresh_process(pkg, name, flags):
     out = subprocess.run([sys.executable, tool, name, str(flags)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == "OK", out.stdout
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_launch_order_feedback_random_walks(pkg, seed):
+    """Sparse random sphere fields (few tiles with hits, so the launch-order lists stay in use) under a camera that
+    drifts, jumps and comes back: every frame must equal the frame of an index-order context, bit for bit."""
+    rng = np.random.default_rng(7000 + seed)
+    w, h = int(rng.integers(300, 700)), int(rng.integers(200, 420))
+    s = pkg.Scene.new(w, h, float(rng.uniform(40, 75)), 3, (0.2, 0.3, 0.4))
+    n = int(rng.integers(3, 12))
+    for i in range(n):
+        c = rng.uniform([-14, -8, 10], [14, 8, 45])
+        s.add_object(pkg.surface_make("sphere", c, [float(rng.uniform(0.4, 2.2))]), rng.uniform(0, 1, 3),
+                     float(rng.uniform(0.2, 0.7)) if (seed % 2 and i % 3 == 0) else 0.0)
+    for i in range(int(rng.integers(1, 6))):
+        if i % 2:
+            s.add_light("spherical", rng.uniform([-20, 5, -5], [20, 25, 30]), rng.uniform(0, 1, 3), float(rng.uniform(50, 400)))
+        else:
+            s.add_light("directional", rng.normal(size=3) + np.array([0, -1.5, 0]), rng.uniform(0, 1, 3), float(rng.uniform(0.3, 1.2)))
+    r = pkg.Renderer(s, device=0)
+    ref = pkg.Renderer(s, device=0, flags=pkg.RT_FLAG_STATIC_ORDER)
+    pos, yaw, pitch = np.array([0.0, 0.0, 0.0]), 90.0, 0.0
+    hits_seen = 0
+    for frame in range(14):
+        kind = rng.integers(0, 4)
+        if kind == 0:      # drift
+            pos = pos + rng.normal(scale=0.3, size=3); yaw += float(rng.normal(scale=2.0))
+        elif kind == 1:    # jump
+            pos = rng.uniform([-10, -4, -5], [10, 6, 8]); yaw = float(rng.uniform(40, 140)); pitch = float(rng.uniform(-15, 15))
+        # kind == 2: look away for one frame (empty frame, the lists go stale); kind == 3: stand still
+        cam = pkg.camera_matrix(tuple(pos), -90.0 if kind == 2 else yaw, pitch)
+        r.update(cam)
+        ref.update(cam)
+        a, b = r.download(), ref.download()
+        assert np.array_equal(a, b), f"seed {seed} frame {frame}"
+        hits_seen += int(np.any(a[..., :3] != np.asarray((0.2, 0.3, 0.4), dtype=np.float32)))
+    assert hits_seen >= 2, "the walk never saw the scene"

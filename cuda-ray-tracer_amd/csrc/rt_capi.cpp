@@ -520,7 +520,7 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
             hip_ok(hipMalloc((void **) &fa.order_state, bytes), "hipMalloc(order)") && hip_ok(hipMemset(fa.order_state, 0, bytes), "hipMemset(order)");
             // the kernel reports the number of listed tiles through one host-mapped word; without it (allocation
             // refused) every launch simply carries n_tiles list slots
-            if (rc == RT_OK && hipHostMalloc((void **) &ctx->h_listed, 64, hipHostMallocMapped) == hipSuccess) {
+            if (rc == RT_OK && hipHostMalloc((void **) &ctx->h_listed, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) {
                 ctx->h_listed[0] = 0;
                 ctx->h_listed[1] = 0;
                 if (hipHostGetDevicePointer((void **) &fa.ord_host, ctx->h_listed, 0) != hipSuccess) {

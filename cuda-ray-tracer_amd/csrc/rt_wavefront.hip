@@ -752,6 +752,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             const uint32_t k = b < e1 ? 0u : (b < e2 ? 1u : (b < e3 ? 2u : 3u));
             const uint32_t first = k == 0 ? 0u : (k == 1 ? e1 : (k == 2 ? e2 : e3));
             tile = ord_rd[RT_ORD_HDR + (1u + k) * fa.n_tiles + (b - first)];
+            if (tile >= fa.n_tiles) return; // never true for lists this kernel wrote; keeps a corrupted list harmless
             listed = true;
         } else {
             tile = idx_tile;
@@ -1084,7 +1085,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 reinterpret_cast<float4 *>(fb)[pix] = make_float4(res.x, res.y, res.z, 1.0f);
             }
         }
-        if (ord_cls) { // thread 0 of a tile with hits, ordering on
+        if (ord_cls && ord_pos < fa.n_tiles) { // thread 0 of a tile with hits, ordering on (the bound can only fail if frames
+                                                // were replayed with stale arguments, e.g. from a captured graph: stay in bounds)
             ord_wr[RT_ORD_HDR + (5u - ord_cls) * fa.n_tiles + ord_pos] = tile;
             ord_wr[RT_ORD_HDR + tile] = (ord_pos << 3) | ord_cls;
         }

@@ -144,7 +144,11 @@ int rt_create(rt_ctx **out, const rt_scene_desc *scene, const rt_config *cfg);
  *   stream  hipStream_t to launch on (NULL = default stream)
  *   ms      if non-NULL: the call synchronises and stores the device time of the render kernels in
  *           milliseconds (hipEvent pair, what the reference's update() returns); if NULL the call only
- *           enqueues work (graph-capture safe). */
+ *           enqueues work.
+ * A context carries a little state from frame to frame (which tiles had hits: the next frame starts those first;
+ * it affects speed only).  Issue a context's frames in order, on one stream at a time; each call passes new
+ * arguments, so replaying a captured graph of it renders correctly but without that ordering (use
+ * RT_FLAG_STATIC_ORDER for contexts that are captured). */
 int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *stream, float *ms);
 
 /* Row ownership: number of local rows, and for local row i its global y (row 0 = bottom of the image,

@@ -977,6 +977,17 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                         // shadow_ray, include/light_impl.h:19-21: (light - point) through FP32
                         max_t = 1.0;
                         const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]}; // re-read: not kept in registers across lights
+                        if (!COUNT) {
+                            // Same argument for a point light behind the surface: the shading term is
+                            // max(0, (float) dot(n, normalize(l - p))) (include/light_impl.h:38-43), normalisation scales by
+                            // a positive factor, so the sign is that of q = dot(n, l - p) unless q is lost in rounding --
+                            // lanes sit out only when q < 0 by a margin 10^7 times the rounding error of either form.
+                            const double dx = lt.p[0] - p.x, dy = lt.p[1] - p.y, dz = lt.p[2] - p.z;
+                            const double q = dot3(nrm, D3{dx, dy, dz});
+                            const double mag = fabs(nrm.x * dx) + fabs(nrm.y * dy) + fabs(nrm.z * dz);
+                            wanted = valid && !(q < -1e-9 * mag);
+                            if (!__any(wanted)) continue;
+                        }
                         const D3 sd{(double) (float) (lt.p[0] - p.x), (double) (float) (lt.p[1] - p.y), (double) (float) (lt.p[2] - p.z)};
                         mono_set_d<NEED_CROSS>(sm, sd);
                     } else {
@@ -1031,6 +1042,10 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 res = F3{spark[tid], spark[WG + tid], spark[2 * WG + tid]};
                 cur_ratio = spark[3 * WG + tid];
                 n_refl = reinterpret_cast<const uint32_t *>(spark)[4 * WG + tid];
+                // ray direction and origin are re-defined here for EVERY lane (only bouncing lanes use them again), so that
+                // neither is live across phases B and C: 12 VGPRs the register allocator otherwise has to carry
+                dir = D3{hdir[tid], hdir[WG + tid], hdir[2 * WG + tid]};
+                o = D3{0.0, 0.0, 0.0};
             }
             if (hit) {
                 const F3 oc{scolor[tid], scolor[WG + tid], scolor[2 * WG + tid]};
@@ -1049,7 +1064,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                         // hit point and normal come back from this lane's queue slot (kept out of registers across B / C)
                         const D3 sp{hp[my_slot], hp[WG + my_slot], hp[2 * WG + my_slot]};
                         const D3 sn{hn[my_slot], hn[WG + my_slot], hn[2 * WG + my_slot]};
-                        dir = reflect_ray(D3{hdir[tid], hdir[WG + tid], hdir[2 * WG + tid]}, sn);
+                        dir = reflect_ray(dir, sn);
                         cnt.add(2);
                         o = D3{sp.x + SHADOW_BIAS * sn.x, sp.y + SHADOW_BIAS * sn.y, sp.z + SHADOW_BIAS * sn.z};
                     }

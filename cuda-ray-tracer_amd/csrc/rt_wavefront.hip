@@ -841,6 +841,17 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         D3 dir = primary_dir(fa, (int) xc, (int) y);
 #endif
         if (covered) return; // workgroup-uniform
+        // A tile that gets here (it passed the tile-level cone test, or was listed, or the scene has no such test) will
+        // almost surely find hits and stage the scene: request this thread's share of the copy now (after the
+        // camera-table reads, so that those can be waited for on their own) and let the latency pass behind phase A
+        // instead of in front of the shadow phase.  Two 16-byte pieces per thread cover 8 KB of tables + lights; larger
+        // scenes copy the rest the ordinary way.
+        const uint4 *stage_scene = reinterpret_cast<const uint4 *>(gscene + fa.off_us);
+        const uint4 *stage_light = reinterpret_cast<const uint4 *>(glight);
+        const uint32_t n16 = fa.stage_bytes / 16, tot16 = n16 + fa.n_lights * (uint32_t) (sizeof(DevLight) / 16);
+        uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
+        if (tid < tot16) pre0 = tid < n16 ? stage_scene[tid] : stage_light[tid - n16];
+        if (tid + WG < tot16) pre1 = tid + WG < n16 ? stage_scene[tid + WG] : stage_light[tid + WG - n16];
         bool live = inside; // this pixel still has a ray to trace
         bool first = true;
         uint32_t ord_cls = 0, ord_pos = 0; // thread 0: this tile's entry in the next frame's launch order
@@ -891,15 +902,11 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             }
             if (n_hits == 0) break; // workgroup-uniform: nothing left to shade or bounce (all lanes are dead by now)
             const uint32_t n_chunks = (n_hits + 63) >> 6;
-            if (!staged) { // first round with hits: bring the scene and the lights into LDS, 16 B per lane per step
-                const uint4 *src = reinterpret_cast<const uint4 *>(gscene + fa.off_us);
+            if (!staged) { // first round with hits: bring the scene and the lights into LDS (one contiguous image), 16 B per lane per step
                 uint4 *dst = reinterpret_cast<uint4 *>(smem + L.scene);
-                const uint32_t n16 = fa.stage_bytes / 16;
-                for (uint32_t i = tid; i < n16; i += WG) dst[i] = src[i];
-                const uint4 *lsrc = reinterpret_cast<const uint4 *>(glight);
-                uint4 *ldst = reinterpret_cast<uint4 *>(smem + L.light);
-                const uint32_t l16 = fa.n_lights * (uint32_t) (sizeof(DevLight) / 16);
-                for (uint32_t i = tid; i < l16; i += WG) ldst[i] = lsrc[i];
+                if (tid < tot16) dst[tid] = pre0; // the first two pieces are already in registers
+                if (tid + WG < tot16) dst[tid + WG] = pre1;
+                for (uint32_t i = tid + 2 * WG; i < tot16; i += WG) dst[i] = i < n16 ? stage_scene[i] : stage_light[i - n16];
                 staged = true;
             }
             uint32_t my_slot = 0;

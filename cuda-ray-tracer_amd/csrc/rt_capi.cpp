@@ -559,6 +559,25 @@ extern "C" int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *
     // g_ray_origin = camera_matrix * (0,0,0,1), src/update-cpu.cpp:123 -- glm order (m0*x + m1*y) + (m2*z + m3*w)
     for (int r = 0; r < 3; r++) fa.origin[r] = (cam[0 + r] * 0.0 + cam[4 + r] * 0.0) + (cam[8 + r] * 0.0 + cam[12 + r] * 1.0);
 
+    { // tile pyramids of the early-out test (FrameArgs::tile_nt): inverse transpose of the camera's 3x3 part
+        const double a = cam[0], b = cam[4], c = cam[8], d = cam[1], e = cam[5], f = cam[9], g = cam[2], h = cam[6], i = cam[10];
+        const double co00 = e * i - f * h, co01 = -(d * i - f * g), co02 = d * h - e * g;
+        const double co10 = -(b * i - c * h), co11 = a * i - c * g, co12 = -(a * h - b * g);
+        const double co20 = b * f - c * e, co21 = -(a * f - c * d), co22 = a * e - b * d;
+        const double det = a * co00 + b * co01 + c * co02;
+        const double amax = std::fabs(a) + std::fabs(b) + std::fabs(c) + std::fabs(d) + std::fabs(e) + std::fabs(f) + std::fabs(g) + std::fabs(h) + std::fabs(i);
+        fa.tile_planes_ok = (std::isfinite(det) && std::isfinite(amax) && std::fabs(det) > 1e-9 * amax * amax * amax) ? 1u : 0u;
+        if (fa.tile_planes_ok) { // (M^-1)^T = cofactor matrix / det; stored column-major: element (row r, col k) at [3 * k + r]
+            const double inv = 1.0 / det;
+            const double nt[9] = {co00 * inv, co10 * inv, co20 * inv, co01 * inv, co11 * inv, co21 * inv, co02 * inv, co12 * inv, co22 * inv};
+            for (int k = 0; k < 9; k++) fa.tile_nt[k] = nt[k];
+        }
+        fa.cx_a = 2.0 * fa.aspect * fa.tan_half_fov / (double) fa.width;
+        fa.cx_b = (1.0 / (double) fa.width - 1.0) * fa.aspect * fa.tan_half_fov;
+        fa.cy_a = 2.0 * fa.tan_half_fov / (double) fa.height;
+        fa.cy_b = (1.0 / (double) fa.height - 1.0) * fa.tan_half_fov;
+        if (!(fa.cx_a > 0.0) || !(fa.cy_a > 0.0) || !std::isfinite(fa.cx_a) || !std::isfinite(fa.cy_a)) fa.tile_planes_ok = 0;
+    }
     int cur = -1;
     RT_HIP(hipGetDevice(&cur));
     if (cur != ctx->device) RT_HIP(hipSetDevice(ctx->device));

@@ -104,6 +104,13 @@ struct FrameArgs {
     uint32_t rgba8;                             // 1: store iround(c*255) RGBA8 instead of RGBA32F
     uint32_t has_mirror;                        // some object has reflection_ratio > EPS
     uint32_t all_cullable;                      // every object is a unit sphere with a finite bounding radius
+    // Tile-level early-out (all_cullable scenes): the rays of a tile are t * M3 * (cx, cy, 1), cx / cy between the tile's
+    // first and last pixel, so they lie inside the pyramid of the planes (M3^-T n) . p >= 0 with n = (1, 0, -cx0),
+    // (-1, 0, cx1), (0, 1, -cy0), (0, -1, cy1), (0, 0, 1).  Set per frame by rt_render:
+    double tile_nt[9];   // M3^-T, column-major (M3 = upper-left 3x3 of cam)
+    double cx_a, cx_b;   // camera-plane x of pixel column x  ~=  cx_a * x + cx_b   (cx_a > 0)
+    double cy_a, cy_b;   // camera-plane y of image row y     ~=  cy_a * y + cy_b   (cy_a > 0)
+    uint32_t tile_planes_ok; // 0: M3 is singular / not finite -- no tile is declared empty this frame
     // Launch-order feedback (wavefront kernel): three generations, ord_stride words apart, of
     //   { count[4] (classes 4,3,2,1), census, pad[11], word[n_tiles], list[4][n_tiles] }     (uint32)
     // word[t] = (position in its class list << 3) | class, written only by tiles with hits (a stale word is harmless: the

@@ -324,6 +324,49 @@ __device__ __forceinline__ bool sphere_in_cone(double kx, double ky, double kz, 
     return rel;
 }
 
+// Tile-level early-out for all-sphere scenes.  The rays of a tile are t * M3 * (cx, cy, 1), t > 0, with cx / cy between
+// the camera-plane coordinates of the tile's first and last pixel (widened by half a pixel), i.e. they lie inside the
+// pyramid of five planes through the ray origin whose normals are M3^-T (1, 0, -cx0), (-1, 0, cx1), (0, 1, -cy0),
+// (0, -1, cy1), (0, 0, 1) (FrameArgs::tile_nt; no normalisation, no division, no square root).  A sphere whose centre lies
+// further than its radius plus the margin of sphere_in_cone outside ANY of the planes cannot be hit by a ray of the tile;
+// the comparison is made on squares.  Purely conservative: the verdict only decides whether phase A runs at all.
+struct TilePlanes {
+    D3 n[5];
+    double nn[5]; // n . n
+};
+
+__device__ __forceinline__ TilePlanes tile_planes(const FrameArgs &fa, double cx0, double cx1, double cy0, double cy1)
+{
+    const D3 c0{fa.tile_nt[0], fa.tile_nt[1], fa.tile_nt[2]}, c1{fa.tile_nt[3], fa.tile_nt[4], fa.tile_nt[5]}, c2{fa.tile_nt[6], fa.tile_nt[7], fa.tile_nt[8]};
+    TilePlanes P;
+    P.n[0] = D3{c0.x - cx0 * c2.x, c0.y - cx0 * c2.y, c0.z - cx0 * c2.z};
+    P.n[1] = D3{cx1 * c2.x - c0.x, cx1 * c2.y - c0.y, cx1 * c2.z - c0.z};
+    P.n[2] = D3{c1.x - cy0 * c2.x, c1.y - cy0 * c2.y, c1.z - cy0 * c2.z};
+    P.n[3] = D3{cy1 * c2.x - c1.x, cy1 * c2.y - c1.y, cy1 * c2.z - c1.z};
+    P.n[4] = c2;
+#pragma unroll
+    for (int k = 0; k < 5; k++) P.nn[k] = dot3(P.n[k], P.n[k]);
+    return P;
+}
+
+__device__ __forceinline__ bool sphere_in_pyramid(double kx, double ky, double kz, double r, double inv_r, const D3 &org, const TilePlanes &P)
+{
+    if (!(r < INFINITY)) return true;
+    const double ccx = -0.5 * kx, ccy = -0.5 * ky, ccz = -0.5 * kz;
+    const D3 v{ccx - org.x, ccy - org.y, ccz - org.z};
+    const double v1 = fabs(v.x) + fabs(v.y) + fabs(v.z);
+    const double s2 = ccx * ccx + ccy * ccy + ccz * ccz + org.x * org.x + org.y * org.y + org.z * org.z;
+    const double lim = r + 1e-6 * (v1 + r + 1.0) + 1e-12 * (s2 + 1.0) * inv_r; // as in sphere_in_cone
+    const double lim2 = lim * lim * (1.0 + 1e-9);
+    bool in = true;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const double f = dot3(P.n[k], v);
+        in = in && !(f < 0.0 && f * f > lim2 * P.nn[k]); // beyond plane k by more than lim: outside
+    }
+    return in;
+}
+
 __device__ __forceinline__ unsigned long long primary_cone_mask(const UsEntry *us, uint32_t base, uint32_t end, const D3 &org,
                                                                 const D3 &axis, double cos_t, uint32_t lane)
 {
@@ -777,32 +820,30 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         const uint32_t y = global_row(fa, lrc);
 
         // ---- tile-level early-out ----
-        // When every object is a cullable sphere, ONE wave first tests the cone of the whole 16x16 tile (axis = the
-        // tile's centre pixel, half-angle from its four corner pixels: the same argument as primary_cone_mask) against
-        // all spheres.  83 % of the tiles of config 2 end here: nothing can be hit, the other three waves never form a
+        // When every object is a cullable sphere, ONE wave first tests the pyramid of the whole 16x16 tile (five planes,
+        // sphere_in_pyramid above: no division or square root on this path, which 83 % of config 2's workgroups take and
+        // nothing else) against all spheres.  A tile that cannot be hit ends here: the other three waves never form a
         // ray, and the tile is just the background colour.
-        if (fa.all_cullable && !listed) { // launch-uniform x workgroup-uniform; a listed tile almost surely has hits again
+        if (fa.all_cullable && fa.tile_planes_ok && !listed) { // launch-uniform x workgroup-uniform; a listed tile almost surely has hits again
             if (wave == 0) {
-                // this lane's sphere (first group of 64) was requested at the top of the kernel; the directions use the
-                // in-kernel divisions of primary_dir (same IEEE operations as the camera tables, hence the same values)
-                // instead of two more dependent global reads
-                const uint32_t tx0 = tile_x * RT_TILE, ty0 = tile_y * RT_TILE;
-                uint32_t sx = tx0 + ((lane == 1 || lane == 3) ? RT_TILE - 1 : (lane >= 4 ? RT_TILE / 2 : 0));
-                uint32_t sy = ty0 + ((lane == 2 || lane == 3) ? RT_TILE - 1 : (lane >= 4 ? RT_TILE / 2 : 0));
-                sx = sx < fa.width ? sx : fa.width - 1;
-                sy = sy < fa.local_rows ? sy : fa.local_rows - 1;
-                const D3 sd = primary_dir(fa, (int) sx, (int) global_row(fa, sy));
-                const D3 axis{readlane_d(sd.x, 4), readlane_d(sd.y, 4), readlane_d(sd.z, 4)};
-                const double ca = dot3(axis, sd);
-                const double c0 = readlane_d(ca, 0), c1 = readlane_d(ca, 1), c2 = readlane_d(ca, 2), c3 = readlane_d(ca, 3);
-                const double m01 = c0 < c1 ? c0 : c1, m23 = c2 < c3 ? c2 : c3;
-                const double cos_t = m01 < m23 ? m01 : m23;
+                // this lane's sphere (first group of 64) was requested at the top of the kernel
+                const uint32_t x0 = tile_x * RT_TILE, y0l = tile_y * RT_TILE;
+                const uint32_t x1 = x0 + RT_TILE - 1 < fa.width ? x0 + RT_TILE - 1 : fa.width - 1;
+                const uint32_t y1l = y0l + RT_TILE - 1 < fa.local_rows ? y0l + RT_TILE - 1 : fa.local_rows - 1;
+                const double gy0 = (double) global_row(fa, y0l), gy1 = (double) global_row(fa, y1l); // increasing in the local row
+                const TilePlanes P = tile_planes(fa, fa.cx_a * ((double) x0 - 0.5) + fa.cx_b, fa.cx_a * ((double) x1 + 0.5) + fa.cx_b,
+                                                 fa.cy_a * (gy0 - 0.5) + fa.cy_b, fa.cy_a * (gy1 + 0.5) + fa.cy_b);
                 const D3 org{fa.origin[0], fa.origin[1], fa.origin[2]};
-                unsigned long long any = __ballot(lane < fa.n_us && sphere_in_cone(pkx, pky, pkz, pr, pinv, org, axis, cos_t));
+                unsigned long long any = __ballot(lane < fa.n_us && sphere_in_pyramid(pkx, pky, pkz, pr, pinv, org, P));
                 if (lane == 0) cnt.add(7, fa.n_us < 64 ? fa.n_us : 64);
                 for (uint32_t base = 64; base < fa.n_us; base += 64) {
                     const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
-                    any |= primary_cone_mask(G.us, base, end, org, axis, cos_t, lane);
+                    bool rel = false;
+                    if (base + lane < end) {
+                        const UsEntry e = G.us[base + lane];
+                        rel = sphere_in_pyramid(e.kx, e.ky, e.kz, e.r, e.inv_r, org, P);
+                    }
+                    any |= __ballot(rel);
                     if (lane == 0) cnt.add(7, end - base);
                 }
                 if (lane == 0) s_live[0] = any != 0ull ? 1u : 0u;

@@ -557,3 +557,25 @@ def test_launch_order_feedback_random_walks(pkg, seed):
         assert np.array_equal(a, b), f"seed {seed} frame {frame}"
         hits_seen += int(np.any(a[..., :3] != np.asarray((0.2, 0.3, 0.4), dtype=np.float32)))
     assert hits_seen >= 2, "the walk never saw the scene"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_general_camera_matrices_on_sphere_fields(pkg, oracle, seed):
+    """update() takes any dmat4, not only the rigid ones the reference's host builds: scaled, sheared and mirrored
+    camera matrices on all-sphere scenes (where the tile-level pyramid test uses the inverse transpose of the 3x3 part)
+    must still match the oracle bit for bit."""
+    rng = np.random.default_rng(9100 + seed)
+    sc = random_scene(pkg, 9100 + seed, int(rng.integers(4, 30)), int(rng.integers(1, 7)), w=int(rng.integers(150, 400)),
+                      h=int(rng.integers(100, 300)), with_plane=False, mirrors=bool(seed % 2))
+    base = pkg.camera_matrix((float(rng.uniform(-3, 3)), float(rng.uniform(-2, 2)), float(rng.uniform(-4, 2))),
+                             float(rng.uniform(70, 110)), float(rng.uniform(-10, 10))).reshape(4, 4).T.copy()   # row-major view
+    lin = np.eye(3) + rng.normal(scale=0.25, size=(3, 3))          # shear + anisotropic scale
+    if seed % 3 == 0:
+        lin[:, 0] *= -1.0                                           # mirrored
+    m = base.copy()
+    m[:3, :3] = base[:3, :3] @ lin
+    cam = np.ascontiguousarray(m.T).reshape(16)                     # back to column-major
+    got = render_desc(pkg, sc, cam)
+    want = oracle_from(pkg, oracle, sc).render(cam=cam, nthreads=8)
+    assert np.array_equal(got[..., :3], want)
+    assert np.array_equal(got, render_desc(pkg, sc, cam, flags=pkg.RT_FLAG_SIMPLE))

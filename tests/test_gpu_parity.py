@@ -579,3 +579,15 @@ def test_general_camera_matrices_on_sphere_fields(pkg, oracle, seed):
     want = oracle_from(pkg, oracle, sc).render(cam=cam, nthreads=8)
     assert np.array_equal(got[..., :3], want)
     assert np.array_equal(got, render_desc(pkg, sc, cam, flags=pkg.RT_FLAG_SIMPLE))
+
+
+@pytest.mark.parametrize("n", [65, 130, 200])
+def test_many_spheres_without_a_plane(pkg, oracle, n):
+    """All-sphere scenes with more than one 64-sphere group: the tile-level pyramid test, the per-wave cone and the
+    shadow-phase culling all loop over groups; frames must match the oracle and the un-culled kernels bit for bit."""
+    sc = random_scene(pkg, 31000 + n, n, 5, w=200, h=150, with_plane=False, mirrors=(n == 130))
+    cam = pkg.camera_matrix((0.5, 1.0, -6.0), 88.0, -3.0)
+    got = render_desc(pkg, sc, cam)
+    assert np.array_equal(got[..., :3], oracle_from(pkg, oracle, sc).render(cam=cam, nthreads=8))
+    assert np.array_equal(got, render_desc(pkg, sc, cam, flags=pkg.RT_FLAG_NOCULL))
+    assert np.array_equal(got, render_desc(pkg, sc, cam, flags=pkg.RT_FLAG_SIMPLE))

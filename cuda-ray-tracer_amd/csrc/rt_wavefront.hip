@@ -681,7 +681,16 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
 // round loop is known to run once and the bounce state (ray direction, blend ratio, depth) is dead during the shadow
 // phase -- which is what lets the mirror-free instantiation fit 128 VGPRs (4 waves per SIMD).
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR>
-__global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MIRROR>())) void wavefront_tile_kernel(const FrameArgs fa, const unsigned char *__restrict__ gscene,
+__global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MIRROR>())) void wavefront_tile_kernel(
+    // The first eight dwords of the kernel arguments are PRELOADED into SGPRs at wave launch (kernarg preload, gfx940+;
+    // the object is built with -amdgpu-kernarg-preload-count=8): with them a workgroup can request its sphere entries
+    // and the launch-order state in its very first instructions, in parallel with the loads of everything else,
+    // instead of one round trip later.  They repeat values of `fa`; rt_launch_wavefront fills both.
+    const unsigned char *hot_us,      // gscene + fa.off_us: the unit-sphere table
+    const uint32_t *hot_ord_rd,       // the launch-order generation this frame reads (fa.order_state + ord_read * ord_stride)
+    uint32_t hot_n_us, uint32_t hot_ord_cap, uint32_t hot_n_tiles,
+    uint32_t hot_flags,               // 1: fa.all_cullable   2: launch-order lists in use (fa.order_state && fa.ord_on)
+    const FrameArgs fa, const unsigned char *__restrict__ gscene,
                                                               const DevLight *__restrict__ glight, void *__restrict__ fb,
                                                               unsigned long long *__restrict__ counters,
                                                               const double *__restrict__ camx, const double *__restrict__ camy)
@@ -744,8 +753,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     // tile-level early-out (below): lane j of wave 0 tests sphere j, whatever the tile -- so the entry is requested
     // before the tile is even known and its latency overlaps with the order-state reads
     double pkx = 0.0, pky = 0.0, pkz = 0.0, pr = 0.0, pinv = 0.0;
-    if (fa.all_cullable && wave == 0 && lane < fa.n_us) {
-        const UsEntry *pe = &G.us[lane];
+    if ((hot_flags & 1u) && wave == 0 && lane < hot_n_us) {
+        const UsEntry *pe = reinterpret_cast<const UsEntry *>(hot_us) + lane;
         pkx = pe->kx; pky = pe->ky; pkz = pe->kz; pr = pe->r; pinv = pe->inv_r;
     }
     uint32_t *ord_wr = nullptr;
@@ -763,16 +772,16 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             if (fa.ord_host) { fa.ord_host[0] = 0; fa.ord_host[1] = ord_rd[4]; }
         }
     }
-    if (fa.order_state && fa.ord_on) { // launch-uniform
+    if (hot_flags & 2u) { // launch-uniform
         // the generation being read was written by the previous launch and is not touched by this one: constant address
         // space, so that the reads become scalar loads (through the generic pointer they are vector loads + readfirstlane)
         typedef const __attribute__((address_space(4))) uint32_t *ConstWords;
-        ConstWords ord_rd = (ConstWords) (fa.order_state + (size_t) fa.ord_read * fa.ord_stride);
+        ConstWords ord_rd = (ConstWords) hot_ord_rd;
         ord_wr = fa.order_state + (size_t) fa.ord_write * fa.ord_stride;
         const uint32_t cn_x = ord_rd[0], cn_y = ord_rd[1], cn_z = ord_rd[2], cn_w = ord_rd[3]; // listed tiles of class 4, 3, 2, 1
         const uint32_t census = ord_rd[4];                          // tiles with hits in the previous frame, 1 in 16 counted
         // the per-tile word of an index-order slot is requested with them (for a list slot: tile 0's, unused)
-        const uint32_t idx_tile = blockIdx.x >= fa.ord_cap ? blockIdx.x - fa.ord_cap : 0u;
+        const uint32_t idx_tile = blockIdx.x >= hot_ord_cap ? blockIdx.x - hot_ord_cap : 0u;
         const uint32_t w = ord_rd[RT_ORD_HDR + idx_tile]; // (position in its class list << 3) | class, 0 = had no hits
         // ask for the camera / frame part of the kernel arguments here, between issuing the order-state reads and using
         // them: otherwise the compiler sinks those loads below the order decode and a workgroup starts with three
@@ -780,33 +789,33 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         asm volatile("" ::"s"(fa.cam[0]), "s"(fa.cam[2]), "s"(fa.cam[5]), "s"(fa.cam[6]), "s"(fa.cam[8]), "s"(fa.cam[10]), "s"(fa.origin[0]),
                      "s"(fa.origin[2]), "s"(fa.aspect), "s"(fa.tan_half_fov), "s"(fa.width), "s"(fa.local_rows), "s"(fa.tiles_x), "s"(fa.n_us),
                      "s"(fa.off_us), "s"(fa.band_rows), "s"(fa.all_cullable), "s"(gscene), "s"(w));
-        listing = census * 64u < fa.n_tiles;                        // the host's switch lags a few frames: same rule here
+        listing = census * 64u < hot_n_tiles;                        // the host's switch lags a few frames: same rule here
         const uint32_t e1 = cn_x, e2 = e1 + cn_y, e3 = e2 + cn_z, n_listed = e3 + cn_w;
-        const uint32_t n_eff = n_listed < fa.ord_cap ? n_listed : fa.ord_cap;
+        const uint32_t n_eff = n_listed < hot_ord_cap ? n_listed : hot_ord_cap;
         if (blockIdx.x == 0 && tid == 0) {
             uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride; // the generation the NEXT frame appends to
             *reinterpret_cast<uint4 *>(z) = make_uint4(0, 0, 0, 0);
             z[4] = 0;
             if (fa.ord_host) { fa.ord_host[0] = n_listed; fa.ord_host[1] = census; } // host-mapped: sizes / switches later launches
         }
-        if (blockIdx.x < fa.ord_cap) {
+        if (blockIdx.x < hot_ord_cap) {
             if (blockIdx.x >= n_eff) return; // workgroup-uniform
             const uint32_t b = blockIdx.x;
             const uint32_t k = b < e1 ? 0u : (b < e2 ? 1u : (b < e3 ? 2u : 3u));
             const uint32_t first = k == 0 ? 0u : (k == 1 ? e1 : (k == 2 ? e2 : e3));
-            tile = ord_rd[RT_ORD_HDR + (1u + k) * fa.n_tiles + (b - first)];
-            if (tile >= fa.n_tiles) return; // never true for lists this kernel wrote; keeps a corrupted list harmless
+            tile = ord_rd[RT_ORD_HDR + (1u + k) * hot_n_tiles + (b - first)];
+            if (tile >= hot_n_tiles) return; // never true for lists this kernel wrote; keeps a corrupted list harmless
             listed = true;
         } else {
             tile = idx_tile;
             // A tile without hits writes nothing, so its word may be left over from an older frame of this generation:
             // the word is only a hint where to look, and the tile counts as covered iff that list entry really names it.
             const uint32_t cls = w & 7u, pos = w >> 3;
-            if (cls >= 1u && cls <= 4u && pos < fa.n_tiles) {
+            if (cls >= 1u && cls <= 4u && pos < hot_n_tiles) {
                 const uint32_t k = 4u - cls;
                 const uint32_t first = k == 0 ? 0u : (k == 1 ? e1 : (k == 2 ? e2 : e3));
                 const uint32_t count = k == 0 ? cn_x : (k == 1 ? cn_y : (k == 2 ? cn_z : cn_w));
-                if (pos < count && first + pos < n_eff) covered = ord_rd[RT_ORD_HDR + (1u + k) * fa.n_tiles + pos] == tile;
+                if (pos < count && first + pos < n_eff) covered = ord_rd[RT_ORD_HDR + (1u + k) * hot_n_tiles + pos] == tile;
             }
         }
     }
@@ -1183,7 +1192,11 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
     const size_t lds = LdsLayout(fa->stage_bytes, fa->n_lights, fa->has_mirror != 0).total;
     const unsigned char *gs = reinterpret_cast<const unsigned char *>(gobj);
     const int sel = (count ? 8 : 0) | (fa->has_mirror ? 4 : 0) | (fa->n_gq ? 2 : 0) | (fa->n_cub ? 1 : 0);
-#define RT_LAUNCH(C, M, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q, M>), grid, block, lds, stream, *fa, gs, glight, fb, counters, camx, camy)
+    const bool ordering = fa->order_state && fa->ord_on;
+    const unsigned char *hot_us = gs + fa->off_us;
+    const uint32_t *hot_ord_rd = ordering ? fa->order_state + (size_t) fa->ord_read * fa->ord_stride : nullptr;
+    const uint32_t hot_flags = (fa->all_cullable ? 1u : 0u) | (ordering ? 2u : 0u);
+#define RT_LAUNCH(C, M, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q, M>), grid, block, lds, stream, hot_us, hot_ord_rd, fa->n_us, fa->ord_cap, fa->n_tiles, hot_flags, *fa, gs, glight, fb, counters, camx, camy)
     switch (sel) {
     case 0: RT_LAUNCH(false, false, false, false); break;
     case 1: RT_LAUNCH(false, false, false, true); break;

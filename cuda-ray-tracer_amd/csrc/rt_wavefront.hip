@@ -11,7 +11,7 @@
 //   k-th mirror bounce) of phases separated by LDS-only workgroup barriers (lds_barrier):
 //
 //   A  nearest hit   one lane per live pixel.  Primary rays: unit spheres are first culled against the wave's
-//                    16x4-pixel ray cone (primary_cone_mask).  Wave-uniform loops over the per-class tables only
+//                    8x8-pixel ray cone (primary_cone_mask).  Wave-uniform loops over the per-class tables only
 //                    form t1, t0 and the sign of the discriminant; the sqrt + divisions of the root solve are
 //                    DEFERRED to a short per-lane loop over the few objects that can hit (a 64-bit candidate mask
 //                    per lane).  Hits are compacted into an LDS queue (ballot prefix + per-wave counts).
@@ -60,6 +60,13 @@ namespace RT_SYM(rtw) {
 using namespace rtm;
 
 constexpr uint32_t WG = 256; // threads per workgroup = pixels per tile
+
+// Pixel of thread `tid` inside its 16x16 tile: wave w owns the 8x8 quadrant (w & 1, w >> 1), lane l the pixel (l & 7, l >> 3)
+// of it.  Square blocks keep a wave's primary rays in a narrow cone (tighter culling than 16x4 strips: the circumscribed
+// circle has 11.3 instead of 16.5 pixels diameter) and make a 64-hit chunk of the queue spatially compact (smaller
+// bounding balls in the shadow phase); a row of the block is still 128 contiguous bytes of RGBA32F framebuffer.
+__device__ __forceinline__ uint32_t tile_px(uint32_t tid) { return ((tid >> 6) & 1u) * 8u + (tid & 7u); }
+__device__ __forceinline__ uint32_t tile_py(uint32_t tid) { return (tid >> 7) * 8u + ((tid >> 3) & 7u); }
 
 // Diagnostic build only (make STAMPS=1): per-phase wave-cycle totals into counters[8..], read with
 // rt_debug_counters().  The product build contains no stamp.
@@ -394,12 +401,12 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
     double cos_t = 1.0;
     const bool cone = PRIMARY && fa.cull;
     if (cone) {
-        // axis = direction of lane 40 (pixel (8, 2) of the wave's 16x4 block).  The angle to the axis is a
+        // axis = direction of lane 36 (pixel (4, 4) of the wave's 8x8 block).  The angle to the axis is a
         // quasi-convex function on the image plane, so over the block it peaks at one of the four corner pixels
-        // (lanes 0, 15, 48, 63): four v_readlane pairs instead of a 64-lane reduction.
-        axis = D3{readlane_d(m.d.x, 40), readlane_d(m.d.y, 40), readlane_d(m.d.z, 40)};
+        // (lanes 0, 7, 56, 63): four v_readlane pairs instead of a 64-lane reduction.
+        axis = D3{readlane_d(m.d.x, 36), readlane_d(m.d.y, 36), readlane_d(m.d.z, 36)};
         const double ca = dot3(axis, m.d);
-        const double c0 = readlane_d(ca, 0), c1 = readlane_d(ca, 15), c2 = readlane_d(ca, 48), c3 = readlane_d(ca, 63);
+        const double c0 = readlane_d(ca, 0), c1 = readlane_d(ca, 7), c2 = readlane_d(ca, 56), c3 = readlane_d(ca, 63);
         const double m01 = c0 < c1 ? c0 : c1, m23 = c2 < c3 ? c2 : c3;
         cos_t = m01 < m23 ? m01 : m23;
     }
@@ -820,9 +827,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         }
     }
     {
-        // pixel of this lane: tile row-major, 16 pixels per row -> a wave covers a 16 x 4 block of the tile
+        // pixel of this lane: each wave covers an 8 x 8 quadrant of the tile (tile_px / tile_py)
         const uint32_t tile_x = tile % fa.tiles_x, tile_y = tile / fa.tiles_x;
-        const uint32_t x = tile_x * RT_TILE + (tid & 15), lr = tile_y * RT_TILE + (tid >> 4);
+        const uint32_t x = tile_x * RT_TILE + tile_px(tid), lr = tile_y * RT_TILE + tile_py(tid);
         const bool inside = x < fa.width && lr < fa.local_rows;
         // lanes outside the image trace a clamped pixel (keeps the wave's primary cone tight); their result is dropped
         const uint32_t xc = x < fa.width ? x : fa.width - 1, lrc = lr < fa.local_rows ? lr : fa.local_rows - 1;
@@ -1143,7 +1150,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         // through all the rounds; one more lever that keeps the mirror instantiations free of scratch spills
         uint32_t tid_ = tid;
         if (HAS_MIRROR) asm volatile("" : "+v"(tid_));
-        const uint32_t sx_ = (tile % fa.tiles_x) * RT_TILE + (tid_ & 15), sy_ = (tile / fa.tiles_x) * RT_TILE + (tid_ >> 4);
+        const uint32_t sx_ = (tile % fa.tiles_x) * RT_TILE + tile_px(tid_), sy_ = (tile / fa.tiles_x) * RT_TILE + tile_py(tid_);
         if (sx_ < fa.width && sy_ < fa.local_rows) {
             const size_t pix = (size_t) sy_ * fa.width + sx_;
             if (fa.rgba8) {

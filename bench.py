@@ -121,6 +121,10 @@ def main():
                          "default on one GPU).  rgba8 = iround(c*255) RGBA8, the format the reference's CUDA back end writes "
                          "(src/update-cuda.cu:149-156); default when the frame is gathered (N > 1): the gather to rank 0 is "
                          "xGMI-bound and a float frame is 4x the bytes of the frame a display needs")
+    ap.add_argument("--gather", default="sparse", choices=["sparse", "dense"],
+                    help="what a rank sends to rank 0 (N > 1, rgba8).  dense = its rows; sparse = only its 16x16 tiles that are not "
+                         "pure background, with their ids, in a fixed-size message (rt_pack_sparse / rt_assemble_sparse): the gather "
+                         "is xGMI-bound and 83 %% of this workload's tiles are background")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the product path). gloo stages the gather through host memory and lets several ranks share "
                          "one GPU: only for rehearsing the N>1 code path on a 1-GPU box")
@@ -190,6 +194,24 @@ def main():
     asm_done = [torch.cuda.Event(), torch.cuda.Event()] if world > 1 else None
     state = {"k": 0}
 
+    # sparse gather: capacity = tiles with content of the busiest rank (one untimed frame) + 25 % + 64, same on every rank
+    sparse = world > 1 and args.gather == "sparse" and args.format == "rgba8"
+    cap = msg_bytes = 0
+    msg = gathered_msg = None
+    if sparse:
+        my_tiles = ((W + 15) // 16) * ((ren.local_rows + 15) // 16)
+        probe = torch.zeros(pkg.Renderer.sparse_bytes(max(my_tiles, 1)), dtype=torch.uint8, device=dev)
+        ren.update(cam, dev_fb=local[0].data_ptr(), stream=stream.cuda_stream, timed=False)
+        ren.pack_sparse(probe.data_ptr(), max(my_tiles, 1), fb_ptr=local[0].data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        need = torch.tensor([int(probe[:4].cpu().numpy().view(np.uint32)[0]), my_tiles], dtype=torch.int64, device=cdev)
+        dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        cap = int(min(int(need[1]), int(need[0]) + int(need[0]) // 4 + 64))
+        msg_bytes = pkg.Renderer.sparse_bytes(cap)
+        msg = [torch.zeros(msg_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        gathered_msg = [torch.zeros((world, msg_bytes), dtype=torch.uint8, device=dev) for _ in range(2)] if root else None
+        del probe
+
     def step():
         k = state["k"]
         state["k"] = k + 1
@@ -202,24 +224,31 @@ def main():
             if root:
                 stream.wait_event(asm_done[b])  # ... and rank 0 has reassembled it out of gathered[b]
         ren.update(cam, dev_fb=local[b].data_ptr(), stream=stream.cuda_stream, timed=False)
+        if sparse:  # this rank's tiles with content -> fixed-size message
+            ren.pack_sparse(msg[b].data_ptr(), cap, fb_ptr=local[b].data_ptr(), stream=stream.cuda_stream)
+        send = msg[b] if sparse else local[b]
+        recv = (gathered_msg[b] if sparse else gathered[b]) if root else None
         if args.backend == "nccl":
             # RCCL gather over xGMI, the only collective of the path; async: the next frame's render is enqueued behind
             # this call without waiting for it
-            works[b] = dist.gather(local[b], list(gathered[b].unbind(0)) if root else None, dst=0, async_op=True)
+            works[b] = dist.gather(send, list(recv.unbind(0)) if root else None, dst=0, async_op=True)
         else:  # rehearsal only: host-staged gather through gloo
-            lc = local[b].cpu()
+            lc = send.cpu()
             gl = [torch.empty_like(lc) for _ in range(world)] if root else None
             works[b] = dist.gather(lc, gl, dst=0, async_op=True)
             works[b].wait()
             if root:
-                gathered[b].copy_(torch.stack(gl))
+                recv.copy_(torch.stack(gl))
         if root:
             with torch.cuda.stream(side):
                 if args.backend == "nccl":
                     works[b].wait()
                 else:
                     side.wait_stream(stream)
-                ren.assemble(gathered[b].data_ptr(), full[b].data_ptr(), stream=side.cuda_stream)
+                if sparse:
+                    ren.assemble_sparse(recv.data_ptr(), cap, full[b].data_ptr(), stream=side.cuda_stream)
+                else:
+                    ren.assemble(recv.data_ptr(), full[b].data_ptr(), stream=side.cuda_stream)
                 asm_done[b].record(side)
 
     for _ in range(args.warmup):
@@ -297,6 +326,13 @@ def main():
         }
         if frame_check is not None:
             result["config"]["gathered_frame_identical_to_single_gpu_frame"] = frame_check
+            if sparse:
+                hdr = gathered_msg[(state["k"] - 1) & 1][:, :8].cpu().numpy().view(np.uint32)
+                result["config"]["gather"] = {"kind": "sparse tiles", "capacity_tiles_per_rank": cap, "bytes_per_rank": msg_bytes,
+                                              "dense_bytes_per_rank": int(mx * W * px_bytes), "tiles_sent_per_rank": [int(v) for v in hdr[:, 0]],
+                                              "overflow": bool(hdr[:, 1].any())}
+            else:
+                result["config"]["gather"] = {"kind": "dense rows", "bytes_per_rank": int(mx * W * px_bytes)}
         if not args.no_cpu_baseline and world == 1:
             O = graft.load_oracle()
             osc = O.load_scene(os.path.join(ROOT, "scenes", scene_name + ".yml")).with_size(W, H, max_refl)

@@ -28,7 +28,8 @@ ABI_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_scene_load_file", "rt_scene_new", "rt_scene_add_object",
     "rt_scene_add_light", "rt_surface_make", "rt_scene_set_size", "rt_scene_set_max_reflections",
     "rt_scene_get_desc", "rt_scene_free", "rt_camera_matrix", "rt_create", "rt_render", "rt_local_rows", "rt_max_local_rows",
-    "rt_row_map", "rt_pixel_bytes", "rt_device_fb", "rt_download", "rt_assemble", "rt_get_counters", "rt_debug_counters", "rt_destroy",
+    "rt_row_map", "rt_pixel_bytes", "rt_device_fb", "rt_download", "rt_assemble", "rt_sparse_bytes", "rt_pack_sparse", "rt_assemble_sparse",
+    "rt_get_counters", "rt_debug_counters", "rt_destroy",
 ]
 
 
@@ -119,6 +120,10 @@ def lib():
         L.rt_device_fb.restype = vp
         L.rt_download.argtypes = [vp, vp, C.c_size_t]
         L.rt_assemble.argtypes = [vp, vp, vp, vp]
+        L.rt_sparse_bytes.argtypes = [C.c_uint32]
+        L.rt_sparse_bytes.restype = C.c_size_t
+        L.rt_pack_sparse.argtypes = [vp, vp, vp, C.c_uint32, vp]
+        L.rt_assemble_sparse.argtypes = [vp, vp, C.c_uint32, vp, vp]
         L.rt_get_counters.argtypes = [vp, C.POINTER(Counters)]
         L.rt_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rt_destroy.argtypes = [vp]
@@ -248,7 +253,8 @@ def desc_from_arrays(width, height, vertical_fov, bg_color, max_reflections, coe
     return d
 
 
-from .sharding import band_rows_of_rank, max_local_rows, assemble_index, gather_to_root, assemble_torch  # noqa: E402,F401
+from .sharding import (band_rows_of_rank, max_local_rows, assemble_index, gather_to_root, assemble_torch, sparse_words, bg_rgba8,  # noqa: E402,F401
+                       pack_sparse_numpy, assemble_sparse_numpy)
 
 
 class Renderer:
@@ -312,6 +318,18 @@ class Renderer:
 
     def assemble(self, gathered_ptr, full_ptr, stream=None):
         _check(lib().rt_assemble(self._h, C.c_void_p(gathered_ptr), C.c_void_p(full_ptr), C.c_void_p(stream) if stream else None))
+
+    # sparse transport of an RGBA8 frame (tiles with content only): see include/mi355rt.h
+    @staticmethod
+    def sparse_bytes(capacity_tiles):
+        return int(lib().rt_sparse_bytes(int(capacity_tiles)))
+
+    def pack_sparse(self, msg_ptr, capacity_tiles, fb_ptr=None, stream=None):
+        _check(lib().rt_pack_sparse(self._h, C.c_void_p(fb_ptr) if fb_ptr else None, C.c_void_p(msg_ptr), int(capacity_tiles),
+                                    C.c_void_p(stream) if stream else None))
+
+    def assemble_sparse(self, gathered_ptr, capacity_tiles, full_ptr, stream=None):
+        _check(lib().rt_assemble_sparse(self._h, C.c_void_p(gathered_ptr), int(capacity_tiles), C.c_void_p(full_ptr), C.c_void_p(stream) if stream else None))
 
     def debug_counters(self):
         out = (C.c_uint64 * 32)()

@@ -27,6 +27,8 @@ extern "C" hipError_t rt_launch_wavefront_fast(const FrameArgs *, const DevObjec
 
 extern "C" size_t rt_wavefront_lds_bytes_strict(uint32_t, uint32_t, int);
 extern "C" hipError_t rt_launch_assemble_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
+extern "C" hipError_t rt_launch_pack_sparse_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
+extern "C" hipError_t rt_launch_assemble_sparse_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 
 namespace {
 
@@ -675,6 +677,39 @@ extern "C" int rt_assemble(rt_ctx *ctx, const void *gathered, void *full, void *
     hipError_t e = rt_launch_assemble_strict(gathered, full, ctx->fa.width, ctx->fa.height, ctx->cfg.world, ctx->cfg.band_rows,
                                              ctx->max_local_rows, ctx->cfg.format == RT_FMT_RGBA8, (hipStream_t) stream);
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "assemble launch failed: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+// background colour as the RGBA8 kernels store it (iround(c * 255), alpha 255), little-endian r | g << 8 | b << 16 | a << 24
+static uint32_t bg_rgba8(const FrameArgs &fa)
+{
+    const uint32_t r = (uint32_t) (unsigned char) (int) (fa.bg[0] * 255.0f + 0.5f), g = (uint32_t) (unsigned char) (int) (fa.bg[1] * 255.0f + 0.5f),
+                   b = (uint32_t) (unsigned char) (int) (fa.bg[2] * 255.0f + 0.5f);
+    return r | (g << 8) | (b << 16) | (255u << 24);
+}
+
+extern "C" size_t rt_sparse_bytes(uint32_t capacity_tiles)
+{
+    return ((size_t) ((4u + capacity_tiles + 3u) & ~3u) + (size_t) capacity_tiles * 256u) * sizeof(uint32_t);
+}
+
+extern "C" int rt_pack_sparse(rt_ctx *ctx, const void *dev_fb, void *dev_msg, uint32_t capacity_tiles, void *stream)
+{
+    if (!ctx || !dev_msg) return fail(RT_ERR_INVALID, "rt_pack_sparse: null argument");
+    if (ctx->cfg.format != RT_FMT_RGBA8) return fail(RT_ERR_INVALID, "rt_pack_sparse: the context does not render RGBA8");
+    hipError_t e = rt_launch_pack_sparse_strict(dev_fb ? dev_fb : ctx->d_fb, dev_msg, ctx->fa.width, ctx->local_rows, bg_rgba8(ctx->fa), capacity_tiles,
+                                                (hipStream_t) stream);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "pack launch failed: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+extern "C" int rt_assemble_sparse(rt_ctx *ctx, const void *gathered, uint32_t capacity_tiles, void *full, void *stream)
+{
+    if (!ctx || !gathered || !full) return fail(RT_ERR_INVALID, "rt_assemble_sparse: null argument");
+    if (ctx->cfg.format != RT_FMT_RGBA8) return fail(RT_ERR_INVALID, "rt_assemble_sparse: the context does not render RGBA8");
+    hipError_t e = rt_launch_assemble_sparse_strict(gathered, full, ctx->fa.width, ctx->fa.height, ctx->cfg.world, ctx->cfg.band_rows, bg_rgba8(ctx->fa),
+                                                    capacity_tiles, (hipStream_t) stream);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "sparse assemble launch failed: %s", hipGetErrorString(e));
     return RT_OK;
 }
 

@@ -219,6 +219,71 @@ __global__ __launch_bounds__(256) void assemble_kernel(const PIX *__restrict__ g
     }
 }
 
+// ---- sparse frame transport (RGBA8) ------------------------------------------------------------------------------------
+// Most tiles of a typical frame are pure background, and the gather to the root (the only collective of the path) is
+// bound by the xGMI links, so a rank can send only its 16x16 tiles that contain something else:
+//   message = { count, overflow, capacity, 0 } + ids[capacity] (padded to 16 B) + tiles[capacity][256] pixels,
+// a fixed size per rank (collectives want equal sizes); `overflow` is set when more than `capacity` tiles qualify.
+// pack_sparse: one wave per local tile, one 16-byte piece (4 pixels of a tile row) per lane.
+__global__ __launch_bounds__(64) void pack_sparse_kernel(const uint32_t *__restrict__ fb, uint32_t width, uint32_t local_rows, uint32_t tiles_x,
+                                                         uint32_t bg, uint32_t cap, uint32_t *__restrict__ msg)
+{
+    const uint32_t tile = blockIdx.x, lane = threadIdx.x;
+    const uint32_t x = (tile % tiles_x) * 16u + (lane & 3u) * 4u, lr = (tile / tiles_x) * 16u + (lane >> 2);
+    uint4 v = make_uint4(bg, bg, bg, bg);
+    if (lr < local_rows) {
+        const uint32_t *row = fb + (size_t) lr * width;
+        if ((width & 3u) == 0u && x + 3u < width) {
+            v = *reinterpret_cast<const uint4 *>(row + x);
+        } else {
+            if (x < width) v.x = row[x];
+            if (x + 1u < width) v.y = row[x + 1u];
+            if (x + 2u < width) v.z = row[x + 2u];
+            if (x + 3u < width) v.w = row[x + 3u];
+        }
+    }
+    const unsigned long long any = __ballot(v.x != bg || v.y != bg || v.z != bg || v.w != bg);
+    if (any == 0ull) return; // wave-uniform
+    uint32_t pos = 0;
+    if (lane == 0) pos = atomicAdd(&msg[0], 1u);
+    pos = __builtin_amdgcn_readfirstlane(pos);
+    if (pos >= cap) {
+        if (lane == 0) msg[1] = 1u;
+        return;
+    }
+    const uint32_t off_tiles = (4u + cap + 3u) & ~3u;
+    if (lane == 0) msg[4u + pos] = tile;
+    reinterpret_cast<uint4 *>(msg + off_tiles)[(size_t) pos * 64u + lane] = v;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(uint32_t *__restrict__ full, size_t n, uint32_t bg)
+{
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) full[i] = bg;
+}
+
+// root: tile j of rank r's message goes back to its pixels of the full frame (band-cyclic rows, like assemble_kernel)
+__global__ __launch_bounds__(64) void scatter_sparse_kernel(const uint32_t *__restrict__ gathered, uint32_t *__restrict__ full, uint32_t width,
+                                                            uint32_t height, uint32_t world, uint32_t band_rows, uint32_t tiles_x, uint32_t cap)
+{
+    const uint32_t r = blockIdx.x / cap, j = blockIdx.x - r * cap, lane = threadIdx.x;
+    const uint32_t off_tiles = (4u + cap + 3u) & ~3u;
+    const size_t msg_words = (size_t) off_tiles + (size_t) cap * 256u;
+    const uint32_t *msg = gathered + (size_t) r * msg_words;
+    const uint32_t count = msg[0] < cap ? msg[0] : cap;
+    if (j >= count) return;
+    const uint32_t tile = msg[4u + j];
+    const uint4 v = reinterpret_cast<const uint4 *>(msg + off_tiles)[(size_t) j * 64u + lane];
+    const uint32_t x = (tile % tiles_x) * 16u + (lane & 3u) * 4u, lr = (tile / tiles_x) * 16u + (lane >> 2);
+    const uint32_t b = lr / band_rows;
+    const uint64_t y = ((uint64_t) b * world + r) * band_rows + (lr - b * band_rows);
+    if (y >= height) return;
+    uint32_t *row = full + (size_t) y * width;
+    if (x < width) row[x] = v.x;
+    if (x + 1u < width) row[x + 1u] = v.y;
+    if (x + 2u < width) row[x + 2u] = v.z;
+    if (x + 3u < width) row[x + 3u] = v.w;
+}
+
 } // namespace RT_SYM(rtk)
 
 extern "C" hipError_t RT_SYM(rt_launch_trace)(const FrameArgs *fa, const DevObject *gobj, const DevLight *glight,
@@ -258,5 +323,32 @@ extern "C" hipError_t RT_SYM(rt_launch_assemble)(const void *gathered, void *ful
     else
         hipLaunchKernelGGL((assemble_kernel<float4>), dim3(blocks), dim3(256), 0, stream,
                            (const float4 *) gathered, (float4 *) full, width, height, world, band_rows, max_local_rows);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t RT_SYM(rt_launch_pack_sparse)(const void *fb, void *msg, uint32_t width, uint32_t local_rows, uint32_t bg, uint32_t cap,
+                                                     hipStream_t stream)
+{
+    using namespace RT_SYM(rtk);
+    hipError_t e = hipMemsetAsync(msg, 0, 16, stream); // count, overflow
+    if (e != hipSuccess) return e;
+    const uint32_t tiles_x = (width + 15u) / 16u, tiles_y = (local_rows + 15u) / 16u;
+    if (tiles_x * tiles_y == 0u || cap == 0u) return hipSuccess;
+    hipLaunchKernelGGL(pack_sparse_kernel, dim3(tiles_x * tiles_y), dim3(64), 0, stream, (const uint32_t *) fb, width, local_rows, tiles_x, bg, cap,
+                       (uint32_t *) msg);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t RT_SYM(rt_launch_assemble_sparse)(const void *gathered, void *full, uint32_t width, uint32_t height, uint32_t world,
+                                                         uint32_t band_rows, uint32_t bg, uint32_t cap, hipStream_t stream)
+{
+    using namespace RT_SYM(rtk);
+    const size_t n = (size_t) width * height;
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t) ((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, stream, (uint32_t *) full, n, bg);
+    if (cap != 0u && world != 0u)
+        hipLaunchKernelGGL(scatter_sparse_kernel, dim3(world * cap), dim3(64), 0, stream, (const uint32_t *) gathered, (uint32_t *) full, width, height,
+                           world, band_rows, (width + 15u) / 16u, cap);
     return hipGetLastError();
 }

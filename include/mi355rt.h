@@ -167,6 +167,17 @@ int rt_download(rt_ctx *ctx, void *host_dst, size_t bytes);
  * Both are device pointers; enqueued on `stream`. */
 int rt_assemble(rt_ctx *ctx, const void *gathered, void *full, void *stream);
 
+/* Sparse transport of an RGBA8 frame (what `rt_assemble` does, with fewer bytes over the links): most 16x16 tiles of a
+ * typical frame are pure background, so a rank may send only the others.  rt_pack_sparse turns this rank's rows
+ * (dev_fb, or the context's own buffer if NULL) into a fixed-size message of rt_sparse_bytes(capacity_tiles) bytes:
+ *   uint32 { count, overflow, 0, 0 }, uint32 ids[capacity] (padded to 16 bytes), capacity x 256 RGBA8 pixels;
+ * `overflow` != 0 means more than capacity_tiles tiles had content (send the dense frame instead).  The root gathers
+ * the messages ([world][rt_sparse_bytes] in rank order) and rt_assemble_sparse rebuilds [height][width] pixels.
+ * The reference has no counterpart (single GPU); the dense gather + rt_assemble stays the general path. */
+size_t rt_sparse_bytes(uint32_t capacity_tiles);
+int rt_pack_sparse(rt_ctx *ctx, const void *dev_fb, void *dev_msg, uint32_t capacity_tiles, void *stream);
+int rt_assemble_sparse(rt_ctx *ctx, const void *gathered_msgs, uint32_t capacity_tiles, void *full, void *stream);
+
 /* Counters of the last render done with RT_FLAG_COUNT. */
 int rt_get_counters(rt_ctx *ctx, rt_counters *out);
 

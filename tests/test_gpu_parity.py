@@ -591,3 +591,49 @@ def test_many_spheres_without_a_plane(pkg, oracle, n):
     assert np.array_equal(got[..., :3], oracle_from(pkg, oracle, sc).render(cam=cam, nthreads=8))
     assert np.array_equal(got, render_desc(pkg, sc, cam, flags=pkg.RT_FLAG_NOCULL))
     assert np.array_equal(got, render_desc(pkg, sc, cam, flags=pkg.RT_FLAG_SIMPLE))
+
+
+@pytest.mark.parametrize("w,h,world,band,name", [(200, 250, 3, 8, "20spheres"), (333, 97, 2, 16, "20spheres"), (256, 160, 4, 5, "reflection_test"),
+                                                 (64, 48, 1, 16, "quadratic")])
+def test_sparse_transport_rebuilds_the_frame(pkg, w, h, world, band, name):
+    """rt_pack_sparse + rt_assemble_sparse (tiles with content + ids, fixed-size messages) == the single-context RGBA8
+    frame, for ragged sizes, widths that are not multiples of 4 or 16, bands that cut through tiles, and a frame where
+    every tile has content; a capacity that is too small raises the overflow flag instead of writing out of bounds."""
+    import torch
+    sc = pkg.Scene.load_from_file(scene_path(name)).set_size(w, h)
+    full = pkg.Renderer(sc, device=0, fmt=pkg.RT_FMT_RGBA8)
+    full.update()
+    want = full.download()
+    rs = [pkg.Renderer(sc, device=0, rank=r, world=world, band_rows=band, fmt=pkg.RT_FMT_RGBA8) for r in range(world)]
+    n_tiles = max(((w + 15) // 16) * ((ren.local_rows + 15) // 16) for ren in rs)
+    for cap in (n_tiles, max(1, n_tiles // 7)):
+        nbytes = pkg.Renderer.sparse_bytes(cap)
+        assert nbytes % 16 == 0
+        msgs = torch.full((world, nbytes), 0xAB, dtype=torch.uint8, device="cuda:0")
+        for r, ren in enumerate(rs):
+            ren.update()
+            ren.pack_sparse(msgs[r].data_ptr(), cap)
+        out = torch.full((h, w, 4), 7, dtype=torch.uint8, device="cuda:0")
+        rs[0].assemble_sparse(msgs.data_ptr(), cap, out.data_ptr())
+        torch.cuda.synchronize()
+        hdr = msgs.cpu().numpy().view(np.uint32)[:, :2]
+        if cap == n_tiles:
+            assert not hdr[:, 1].any()
+            assert np.array_equal(out.cpu().numpy(), want)
+            # the device messages hold the same (id -> tile) pairs as the host-side mirror (the order is free) and the
+            # mirror rebuilds the same frame from them
+            bgw = pkg.bg_rgba8(sc.arrays()["bg_color"])
+            words = msgs.cpu().numpy().view(np.uint32)
+            off = (4 + cap + 3) & ~3
+            for r, ren in enumerate(rs):
+                ref = pkg.pack_sparse_numpy(ren.download(), ren.local_rows, bgw, cap)
+                assert words[r][0] == ref[0]
+                dev = {int(words[r][4 + j]): words[r][off + j * 256: off + (j + 1) * 256].tobytes() for j in range(int(words[r][0]))}
+                host = {int(ref[4 + j]): ref[off + j * 256: off + (j + 1) * 256].tobytes() for j in range(int(ref[0]))}
+                assert dev == host
+            assert np.array_equal(pkg.assemble_sparse_numpy(words, w, h, band, world, bgw, cap), want)
+        else:
+            overflowed = hdr[:, 0] > cap
+            assert np.array_equal(hdr[:, 1] != 0, overflowed)
+            if not overflowed.any():
+                assert np.array_equal(out.cpu().numpy(), want)

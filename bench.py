@@ -123,7 +123,7 @@ def main():
                          "xGMI-bound and a float frame is 4x the bytes of the frame a display needs")
     ap.add_argument("--gather", default="sparse", choices=["sparse", "dense"],
                     help="what a rank sends to rank 0 (N > 1, rgba8).  dense = its rows; sparse = only its 16x16 tiles that are not "
-                         "pure background, with their ids, in a fixed-size message (rt_pack_sparse / rt_assemble_sparse): the gather "
+                         "pure background, with their ids, in a fixed-size message (rt_render_sparse / rt_assemble_sparse): the gather "
                          "is xGMI-bound and 83 %% of this workload's tiles are background")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the product path). gloo stages the gather through host memory and lets several ranks share "
@@ -201,8 +201,7 @@ def main():
     if sparse:
         my_tiles = ((W + 15) // 16) * ((ren.local_rows + 15) // 16)
         probe = torch.zeros(pkg.Renderer.sparse_bytes(max(my_tiles, 1)), dtype=torch.uint8, device=dev)
-        ren.update(cam, dev_fb=local[0].data_ptr(), stream=stream.cuda_stream, timed=False)
-        ren.pack_sparse(probe.data_ptr(), max(my_tiles, 1), fb_ptr=local[0].data_ptr(), stream=stream.cuda_stream)
+        ren.update_sparse(probe.data_ptr(), max(my_tiles, 1), cam, stream=stream.cuda_stream, timed=False)
         torch.cuda.synchronize()
         need = torch.tensor([int(probe[:4].cpu().numpy().view(np.uint32)[0]), my_tiles], dtype=torch.int64, device=cdev)
         dist.all_reduce(need, op=dist.ReduceOp.MAX)
@@ -223,9 +222,10 @@ def main():
             works[b].wait()                     # frame k-2 has left local[b] (stream-side wait for NCCL, host wait for gloo)
             if root:
                 stream.wait_event(asm_done[b])  # ... and rank 0 has reassembled it out of gathered[b]
-        ren.update(cam, dev_fb=local[b].data_ptr(), stream=stream.cuda_stream, timed=False)
-        if sparse:  # this rank's tiles with content -> fixed-size message
-            ren.pack_sparse(msg[b].data_ptr(), cap, fb_ptr=local[b].data_ptr(), stream=stream.cuda_stream)
+        if sparse:  # the kernel writes this rank's tiles with hits straight into the fixed-size message
+            ren.update_sparse(msg[b].data_ptr(), cap, cam, stream=stream.cuda_stream, timed=False)
+        else:
+            ren.update(cam, dev_fb=local[b].data_ptr(), stream=stream.cuda_stream, timed=False)
         send = msg[b] if sparse else local[b]
         recv = (gathered_msg[b] if sparse else gathered[b]) if root else None
         if args.backend == "nccl":

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_scene_load_file", "rt_scene_new", "rt_scene_add_object",
     "rt_scene_add_light", "rt_surface_make", "rt_scene_set_size", "rt_scene_set_max_reflections",
     "rt_scene_get_desc", "rt_scene_free", "rt_camera_matrix", "rt_create", "rt_render", "rt_local_rows", "rt_max_local_rows",
-    "rt_row_map", "rt_pixel_bytes", "rt_device_fb", "rt_download", "rt_assemble", "rt_sparse_bytes", "rt_pack_sparse", "rt_assemble_sparse",
+    "rt_row_map", "rt_pixel_bytes", "rt_device_fb", "rt_download", "rt_assemble", "rt_sparse_bytes", "rt_render_sparse", "rt_pack_sparse", "rt_assemble_sparse",
     "rt_get_counters", "rt_debug_counters", "rt_destroy",
 ]
 
@@ -123,6 +123,7 @@ def lib():
         L.rt_sparse_bytes.argtypes = [C.c_uint32]
         L.rt_sparse_bytes.restype = C.c_size_t
         L.rt_pack_sparse.argtypes = [vp, vp, vp, C.c_uint32, vp]
+        L.rt_render_sparse.argtypes = [vp, dp, vp, C.c_uint32, vp, fp]
         L.rt_assemble_sparse.argtypes = [vp, vp, C.c_uint32, vp, vp]
         L.rt_get_counters.argtypes = [vp, C.POINTER(Counters)]
         L.rt_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -323,6 +324,14 @@ class Renderer:
     @staticmethod
     def sparse_bytes(capacity_tiles):
         return int(lib().rt_sparse_bytes(int(capacity_tiles)))
+
+    def update_sparse(self, msg_ptr, capacity_tiles, cam=None, stream=None, timed=True):
+        """update() whose output is a sparse message (tiles with hits only) instead of a framebuffer."""
+        cam = np.ascontiguousarray(IDENTITY if cam is None else cam, dtype=np.float64).reshape(16)
+        ms = C.c_float(0.0)
+        _check(lib().rt_render_sparse(self._h, _dptr(cam), C.c_void_p(msg_ptr), int(capacity_tiles), C.c_void_p(stream) if stream else None,
+                                      C.byref(ms) if timed else None))
+        return ms.value if timed else None
 
     def pack_sparse(self, msg_ptr, capacity_tiles, fb_ptr=None, stream=None):
         _check(lib().rt_pack_sparse(self._h, C.c_void_p(fb_ptr) if fb_ptr else None, C.c_void_p(msg_ptr), int(capacity_tiles),

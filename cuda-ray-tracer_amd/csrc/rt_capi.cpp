@@ -552,11 +552,12 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
     return RT_OK;
 }
 
-extern "C" int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *stream_, float *ms)
+static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *stream_, float *ms, bool sparse, uint32_t sparse_cap)
 {
-    if (!ctx || !cam) return fail(RT_ERR_INVALID, "rt_render: null argument");
     hipStream_t stream = (hipStream_t) stream_;
     FrameArgs &fa = ctx->fa;
+    fa.sparse = sparse ? 1u : 0u;
+    fa.sparse_cap = sparse ? sparse_cap : 0u;
     std::memcpy(fa.cam, cam, sizeof(double) * 16);
     // g_ray_origin = camera_matrix * (0,0,0,1), src/update-cpu.cpp:123 -- glm order (m0*x + m1*y) + (m2*z + m3*w)
     for (int r = 0; r < 3; r++) fa.origin[r] = (cam[0 + r] * 0.0 + cam[4 + r] * 0.0) + (cam[8 + r] * 0.0 + cam[12 + r] * 1.0);
@@ -585,6 +586,7 @@ extern "C" int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *
     if (cur != ctx->device) RT_HIP(hipSetDevice(ctx->device));
 
     void *fb = dev_fb ? dev_fb : ctx->d_fb;
+    if (sparse) RT_HIP(hipMemsetAsync(fb, 0, 16, stream)); // message header: count, overflow
     const int count = (ctx->cfg.flags & RT_FLAG_COUNT) ? 1 : 0;
     const int rgba8 = ctx->cfg.format == RT_FMT_RGBA8;
     if (count || ctx->zero_counters) RT_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * 28, stream));
@@ -629,6 +631,20 @@ extern "C" int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *
         RT_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
     }
     return RT_OK;
+}
+
+extern "C" int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *stream, float *ms)
+{
+    if (!ctx || !cam) return fail(RT_ERR_INVALID, "rt_render: null argument");
+    return render_impl(ctx, cam, dev_fb, stream, ms, false, 0);
+}
+
+extern "C" int rt_render_sparse(rt_ctx *ctx, const double cam[16], void *dev_msg, uint32_t capacity_tiles, void *stream, float *ms)
+{
+    if (!ctx || !cam || !dev_msg) return fail(RT_ERR_INVALID, "rt_render_sparse: null argument");
+    if (ctx->cfg.format != RT_FMT_RGBA8) return fail(RT_ERR_INVALID, "rt_render_sparse: the context does not render RGBA8");
+    if (ctx->cfg.flags & RT_FLAG_SIMPLE) return fail(RT_ERR_INVALID, "rt_render_sparse: not available with RT_FLAG_SIMPLE");
+    return render_impl(ctx, cam, dev_msg, stream, ms, true, capacity_tiles);
 }
 
 extern "C" int rt_local_rows(const rt_ctx *ctx, uint32_t *n_rows)

@@ -111,6 +111,9 @@ struct FrameArgs {
     double cx_a, cx_b;   // camera-plane x of pixel column x  ~=  cx_a * x + cx_b   (cx_a > 0)
     double cy_a, cy_b;   // camera-plane y of image row y     ~=  cy_a * y + cy_b   (cy_a > 0)
     uint32_t tile_planes_ok; // 0: M3 is singular / not finite -- no tile is declared empty this frame
+    // Sparse output (rt_render_sparse, RGBA8): the framebuffer argument is a message in rt_pack_sparse's layout; tiles with
+    // round-0 hits take a slot each, background tiles are not stored.
+    uint32_t sparse, sparse_cap;
     // Launch-order feedback (wavefront kernel): three generations, ord_stride words apart, of
     //   { count[4] (classes 4,3,2,1), census, pad[11], word[n_tiles], list[4][n_tiles] }     (uint32)
     // word[t] = (position in its class list << 3) | class, written only by tiles with hits (a stale word is harmless: the

@@ -580,7 +580,7 @@ struct LdsLayout {
         color = off; off = align16(off + 3 * WG * 4);
         shadow = off; off = align16(off + WG * shadow_words * 4);
         ball = off; off = align16(off + 4 * (uint32_t) sizeof(Ball));
-        misc = off; off = align16(off + 32);
+        misc = off; off = align16(off + 48);
         total = off;
     }
 };
@@ -731,6 +731,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     Ball *sball = reinterpret_cast<Ball *>(smem + L.ball);
     uint32_t *s_wcount = reinterpret_cast<uint32_t *>(smem + L.misc); // [4] hits found by each wave this round
     uint32_t *s_live = s_wcount + 4;                                  // [4] per-wave "still bouncing" flags
+    uint32_t *s_sparse = s_wcount + 8;                                // [1] sparse output: this tile's slot in the message (or none)
 
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     RT_STAMP_DECL
@@ -867,7 +868,10 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             if (covered) return; // workgroup-uniform
             lds_barrier();
             if (s_live[0] == 0) { // workgroup-uniform: the tile is pure background (src/update-cpu.cpp:93-95)
-                if (inside) {
+                if (inside && fa.sparse) { // sparse output: background tiles are not stored at all
+                    cnt.add(0);
+                    cnt.add(3, fa.n_obj);
+                } else if (inside) {
                     cnt.add(0);
                     cnt.add(3, fa.n_obj);
                     const size_t pix = (size_t) lr * fa.width + x;
@@ -912,6 +916,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         bool live = inside; // this pixel still has a ray to trace
         bool first = true;
         uint32_t ord_cls = 0, ord_pos = 0; // thread 0: this tile's entry in the next frame's launch order
+        uint32_t sp_pos = 0xFFFFFFFFu;     // thread 0, sparse output: this tile's slot in the message
+        if (fa.sparse && tid == 0) s_sparse[0] = 0xFFFFFFFFu; // visible after the first barrier of round 0
         float cur_ratio = 1.0f;
         uint32_t n_refl = 0;
         if (inside) cnt.add(0);
@@ -950,6 +956,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             RT_STAMP(4);
             const uint32_t c0 = s_wcount[0], c1 = s_wcount[1], c2 = s_wcount[2], c3 = s_wcount[3];
             const uint32_t n_hits = c0 + c1 + c2 + c3;
+            if (first && fa.sparse && tid == 0 && n_hits) // sparse output: a tile with hits takes a slot of the message; the slot
+                sp_pos = atomicAdd(reinterpret_cast<uint32_t *>(fb), 1u); // number is published at phase C, used at the final store
             if (first && ord_wr && tid == 0 && n_hits) { // the next frame's launch order: round-0 hits in four cost classes
                 if (((tile * 0x9E3779B1u) >> 28) == 0u) atomicAdd(&ord_wr[4], 1u); // census, also while the ordering is off
                 if (listing) {
@@ -1076,6 +1084,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             RT_STAMP(7);
 
             // ---------------- phase C: shade each hit, lights in order ----------------
+            if (first && fa.sparse && tid == 0) s_sparse[0] = sp_pos; // the barrier after this phase publishes it
             if (tid < n_hits) {
                 const uint32_t h = tid;
                 const D3 p{hp[h], hp[WG + h], hp[2 * WG + h]};
@@ -1151,7 +1160,22 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         uint32_t tid_ = tid;
         if (HAS_MIRROR) asm volatile("" : "+v"(tid_));
         const uint32_t sx_ = (tile % fa.tiles_x) * RT_TILE + tile_px(tid_), sy_ = (tile / fa.tiles_x) * RT_TILE + tile_py(tid_);
-        if (sx_ < fa.width && sy_ < fa.local_rows) {
+        if (fa.sparse) { // launch-uniform: fb is a message (rt_pack_sparse's layout); only tiles with round-0 hits are in it
+            const uint32_t slot = s_sparse[0]; // workgroup-uniform
+            uint32_t *msg = reinterpret_cast<uint32_t *>(fb);
+            if (slot < fa.sparse_cap) {
+                uchar4 px;
+                px.x = (unsigned char) (int) (res.x * 255.0f + 0.5f);
+                px.y = (unsigned char) (int) (res.y * 255.0f + 0.5f);
+                px.z = (unsigned char) (int) (res.z * 255.0f + 0.5f);
+                px.w = 255;
+                const uint32_t off_tiles = (4u + fa.sparse_cap + 3u) & ~3u;
+                reinterpret_cast<uchar4 *>(msg + off_tiles)[(size_t) slot * 256u + tile_py(tid_) * 16u + tile_px(tid_)] = px;
+                if (tid == 0) msg[4u + slot] = tile;
+            } else if (slot != 0xFFFFFFFFu && tid == 0) {
+                msg[1] = 1u; // more tiles with hits than the message holds
+            }
+        } else if (sx_ < fa.width && sy_ < fa.local_rows) {
             const size_t pix = (size_t) sy_ * fa.width + sx_;
             if (fa.rgba8) {
                 uchar4 px;

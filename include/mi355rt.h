@@ -175,6 +175,9 @@ int rt_assemble(rt_ctx *ctx, const void *gathered, void *full, void *stream);
  * the messages ([world][rt_sparse_bytes] in rank order) and rt_assemble_sparse rebuilds [height][width] pixels.
  * The reference has no counterpart (single GPU); the dense gather + rt_assemble stays the general path. */
 size_t rt_sparse_bytes(uint32_t capacity_tiles);
+/* rt_render that writes such a message directly (tiles in which a primary ray hit something; background tiles are not
+ * stored anywhere): one kernel instead of render + pack, and no local framebuffer.  Arguments as rt_render. */
+int rt_render_sparse(rt_ctx *ctx, const double cam[16], void *dev_msg, uint32_t capacity_tiles, void *stream, float *ms);
 int rt_pack_sparse(rt_ctx *ctx, const void *dev_fb, void *dev_msg, uint32_t capacity_tiles, void *stream);
 int rt_assemble_sparse(rt_ctx *ctx, const void *gathered_msgs, uint32_t capacity_tiles, void *full, void *stream);
 

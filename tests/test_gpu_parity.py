@@ -637,3 +637,34 @@ def test_sparse_transport_rebuilds_the_frame(pkg, w, h, world, band, name):
             assert np.array_equal(hdr[:, 1] != 0, overflowed)
             if not overflowed.any():
                 assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("w,h,world,band,name", [(200, 250, 3, 8, "20spheres"), (333, 97, 2, 16, "20spheres"), (256, 160, 4, 5, "reflection_test"),
+                                                 (640, 360, 1, 16, "20spheres")])
+def test_render_sparse_equals_render_plus_pack(pkg, w, h, world, band, name):
+    """rt_render_sparse writes the message itself (no framebuffer, no pack kernel): rebuilt on the root it must equal
+    the dense RGBA8 frame, three frames in a row (launch-order feedback active), and a capacity that is too small must
+    only raise the overflow flag."""
+    import torch
+    sc = pkg.Scene.load_from_file(scene_path(name)).set_size(w, h)
+    full = pkg.Renderer(sc, device=0, fmt=pkg.RT_FMT_RGBA8)
+    full.update()
+    want = full.download()
+    rs = [pkg.Renderer(sc, device=0, rank=r, world=world, band_rows=band, fmt=pkg.RT_FMT_RGBA8) for r in range(world)]
+    n_tiles = max(((w + 15) // 16) * ((ren.local_rows + 15) // 16) for ren in rs)
+    for cap in (n_tiles, max(1, n_tiles // 9)):
+        nbytes = pkg.Renderer.sparse_bytes(cap)
+        for frame in range(3):
+            msgs = torch.full((world, nbytes), 0xCD, dtype=torch.uint8, device="cuda:0")
+            for r, ren in enumerate(rs):
+                ren.update_sparse(msgs[r].data_ptr(), cap)
+            out = torch.full((h, w, 4), 9, dtype=torch.uint8, device="cuda:0")
+            rs[0].assemble_sparse(msgs.data_ptr(), cap, out.data_ptr())
+            torch.cuda.synchronize()
+            hdr = msgs.cpu().numpy().view(np.uint32)[:, :2]
+            overflowed = hdr[:, 0] > cap
+            assert np.array_equal(hdr[:, 1] != 0, overflowed), (cap, frame)
+            if not overflowed.any():
+                assert np.array_equal(out.cpu().numpy(), want), (cap, frame)
+        if cap == n_tiles:
+            assert not overflowed.any()

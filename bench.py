@@ -189,9 +189,7 @@ def main():
     local = [torch.empty((mx, W, 4), dtype=px_dtype, device=dev) for _ in range(2 if world > 1 else 1)]
     gathered = [torch.empty((world, mx, W, 4), dtype=px_dtype, device=dev) for _ in range(2)] if (root and world > 1) else None
     full = [torch.empty((H, W, 4), dtype=px_dtype, device=dev) for _ in range(2)] if (root and world > 1) else None
-    side = torch.cuda.Stream(device=dev) if world > 1 else None      # root: waits for the gather, reassembles
     works = [None, None]
-    asm_done = [torch.cuda.Event(), torch.cuda.Event()] if world > 1 else None
     state = {"k": 0}
 
     # sparse gather: capacity = tiles with content of the busiest rank (one untimed frame) + 25 % + 64, same on every rank
@@ -211,7 +209,20 @@ def main():
         gathered_msg = [torch.zeros((world, msg_bytes), dtype=torch.uint8, device=dev) for _ in range(2)] if root else None
         del probe
 
+    def assemble(b):
+        """root: turn what gather b delivered into the full frame b (same stream: no side stream, no events -- the host
+        cost of this Python loop matters at 60 us per frame)."""
+        if args.backend == "nccl":
+            works[b].wait()   # stream-side: the render stream waits for the collective, the host does not
+        recv = gathered_msg[b] if sparse else gathered[b]
+        if sparse:
+            ren.assemble_sparse(recv.data_ptr(), cap, full[b].data_ptr(), stream=stream.cuda_stream)
+        else:
+            ren.assemble(recv.data_ptr(), full[b].data_ptr(), stream=stream.cuda_stream)
+
     def step():
+        """One frame per rank.  Pipelined over two buffer sets: the gather of frame k travels while frame k+1 renders,
+        and rank 0 reassembles frame k-1 behind its own render of frame k (everything on one stream per rank)."""
         k = state["k"]
         state["k"] = k + 1
         if world == 1:
@@ -219,9 +230,7 @@ def main():
             return
         b = k & 1
         if works[b] is not None:
-            works[b].wait()                     # frame k-2 has left local[b] (stream-side wait for NCCL, host wait for gloo)
-            if root:
-                stream.wait_event(asm_done[b])  # ... and rank 0 has reassembled it out of gathered[b]
+            works[b].wait()   # frame k-2 has left its send buffer (stream-side wait for NCCL, already complete for gloo)
         if sparse:  # the kernel writes this rank's tiles with hits straight into the fixed-size message
             ren.update_sparse(msg[b].data_ptr(), cap, cam, stream=stream.cuda_stream, timed=False)
         else:
@@ -230,7 +239,8 @@ def main():
         recv = (gathered_msg[b] if sparse else gathered[b]) if root else None
         if args.backend == "nccl":
             # RCCL gather over xGMI, the only collective of the path; async: the next frame's render is enqueued behind
-            # this call without waiting for it
+            # this call without waiting for it.  (It starts after the work already on this stream, so rank 0's reassembly
+            # of frame k-2 out of the same receive buffer is finished by then.)
             works[b] = dist.gather(send, list(recv.unbind(0)) if root else None, dst=0, async_op=True)
         else:  # rehearsal only: host-staged gather through gloo
             lc = send.cpu()
@@ -239,20 +249,17 @@ def main():
             works[b].wait()
             if root:
                 recv.copy_(torch.stack(gl))
-        if root:
-            with torch.cuda.stream(side):
-                if args.backend == "nccl":
-                    works[b].wait()
-                else:
-                    side.wait_stream(stream)
-                if sparse:
-                    ren.assemble_sparse(recv.data_ptr(), cap, full[b].data_ptr(), stream=side.cuda_stream)
-                else:
-                    ren.assemble(recv.data_ptr(), full[b].data_ptr(), stream=side.cuda_stream)
-                asm_done[b].record(side)
+        if root and k >= 1:
+            assemble((k - 1) & 1)   # the previous frame: its gather had a whole render to arrive
+
+    def flush():
+        """root: reassemble the last frame (inside the timed region: K steps deliver K full frames)."""
+        if world > 1 and root and state["k"] >= 1:
+            assemble((state["k"] - 1) & 1)
 
     for _ in range(args.warmup):
         step()
+    flush()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if world > 1:
         dist.barrier()
@@ -261,6 +268,7 @@ def main():
     ev0.record(stream)
     for _ in range(args.steps):
         step()
+    flush()
     ev1.record(stream)
     torch.cuda.synchronize()
     if world > 1:

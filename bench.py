@@ -195,7 +195,7 @@ def main():
     # sparse gather: capacity = tiles with content of the busiest rank (one untimed frame) + 25 % + 64, same on every rank
     sparse = world > 1 and args.gather == "sparse" and args.format == "rgba8"
     cap = msg_bytes = 0
-    msg = gathered_msg = None
+    msg = gathered_msg = stamps = asm_tag = None
     if sparse:
         my_tiles = ((W + 15) // 16) * ((ren.local_rows + 15) // 16)
         probe = torch.zeros(pkg.Renderer.sparse_bytes(max(my_tiles, 1)), dtype=torch.uint8, device=dev)
@@ -207,6 +207,8 @@ def main():
         msg_bytes = pkg.Renderer.sparse_bytes(cap)
         msg = [torch.zeros(msg_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
         gathered_msg = [torch.zeros((world, msg_bytes), dtype=torch.uint8, device=dev) for _ in range(2)] if root else None
+        stamps = [torch.zeros(ren.sparse_stamp_bytes(), dtype=torch.uint8, device=dev) for _ in range(2)] if root else None
+        asm_tag = [0, 0]  # per output buffer: 0 = first reassembly (paints everything), then 1, 2, ...
         del probe
 
     def assemble(b):
@@ -215,8 +217,9 @@ def main():
         if args.backend == "nccl":
             works[b].wait()   # stream-side: the render stream waits for the collective, the host does not
         recv = gathered_msg[b] if sparse else gathered[b]
-        if sparse:
-            ren.assemble_sparse(recv.data_ptr(), cap, full[b].data_ptr(), stream=stream.cuda_stream)
+        if sparse:  # incremental: each output buffer keeps its frame, only tiles that lost their content are repainted
+            ren.assemble_sparse_incremental(recv.data_ptr(), cap, full[b].data_ptr(), stamps[b].data_ptr(), asm_tag[b], stream=stream.cuda_stream)
+            asm_tag[b] = 1 if asm_tag[b] >= 0xFFFFFFF0 else asm_tag[b] + 1
         else:
             ren.assemble(recv.data_ptr(), full[b].data_ptr(), stream=stream.cuda_stream)
 

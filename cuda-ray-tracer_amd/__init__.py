@@ -28,7 +28,8 @@ ABI_SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_scene_load_file", "rt_scene_new", "rt_scene_add_object",
     "rt_scene_add_light", "rt_surface_make", "rt_scene_set_size", "rt_scene_set_max_reflections",
     "rt_scene_get_desc", "rt_scene_free", "rt_camera_matrix", "rt_create", "rt_render", "rt_local_rows", "rt_max_local_rows",
-    "rt_row_map", "rt_pixel_bytes", "rt_device_fb", "rt_download", "rt_assemble", "rt_sparse_bytes", "rt_render_sparse", "rt_pack_sparse", "rt_assemble_sparse",
+    "rt_row_map", "rt_pixel_bytes", "rt_device_fb", "rt_download", "rt_assemble", "rt_sparse_bytes", "rt_render_sparse", "rt_pack_sparse", "rt_assemble_sparse", "rt_sparse_stamp_bytes",
+    "rt_assemble_sparse_incremental",
     "rt_get_counters", "rt_debug_counters", "rt_destroy",
 ]
 
@@ -125,6 +126,9 @@ def lib():
         L.rt_pack_sparse.argtypes = [vp, vp, vp, C.c_uint32, vp]
         L.rt_render_sparse.argtypes = [vp, dp, vp, C.c_uint32, vp, fp]
         L.rt_assemble_sparse.argtypes = [vp, vp, C.c_uint32, vp, vp]
+        L.rt_sparse_stamp_bytes.argtypes = [vp]
+        L.rt_sparse_stamp_bytes.restype = C.c_size_t
+        L.rt_assemble_sparse_incremental.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp]
         L.rt_get_counters.argtypes = [vp, C.POINTER(Counters)]
         L.rt_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rt_destroy.argtypes = [vp]
@@ -339,6 +343,13 @@ class Renderer:
 
     def assemble_sparse(self, gathered_ptr, capacity_tiles, full_ptr, stream=None):
         _check(lib().rt_assemble_sparse(self._h, C.c_void_p(gathered_ptr), int(capacity_tiles), C.c_void_p(full_ptr), C.c_void_p(stream) if stream else None))
+
+    def sparse_stamp_bytes(self):
+        return int(lib().rt_sparse_stamp_bytes(self._h))
+
+    def assemble_sparse_incremental(self, gathered_ptr, capacity_tiles, full_ptr, stamps_ptr, frame_tag, stream=None):
+        _check(lib().rt_assemble_sparse_incremental(self._h, C.c_void_p(gathered_ptr), int(capacity_tiles), C.c_void_p(full_ptr), C.c_void_p(stamps_ptr),
+                                                    int(frame_tag), C.c_void_p(stream) if stream else None))
 
     def debug_counters(self):
         out = (C.c_uint64 * 32)()

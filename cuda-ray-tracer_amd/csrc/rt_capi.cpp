@@ -28,7 +28,7 @@ extern "C" hipError_t rt_launch_wavefront_fast(const FrameArgs *, const DevObjec
 extern "C" size_t rt_wavefront_lds_bytes_strict(uint32_t, uint32_t, int);
 extern "C" hipError_t rt_launch_assemble_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" hipError_t rt_launch_pack_sparse_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
-extern "C" hipError_t rt_launch_assemble_sparse_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
+extern "C" hipError_t rt_launch_assemble_sparse_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, void *, uint32_t, uint32_t, hipStream_t);
 
 namespace {
 
@@ -724,7 +724,26 @@ extern "C" int rt_assemble_sparse(rt_ctx *ctx, const void *gathered, uint32_t ca
     if (!ctx || !gathered || !full) return fail(RT_ERR_INVALID, "rt_assemble_sparse: null argument");
     if (ctx->cfg.format != RT_FMT_RGBA8) return fail(RT_ERR_INVALID, "rt_assemble_sparse: the context does not render RGBA8");
     hipError_t e = rt_launch_assemble_sparse_strict(gathered, full, ctx->fa.width, ctx->fa.height, ctx->cfg.world, ctx->cfg.band_rows, bg_rgba8(ctx->fa),
-                                                    capacity_tiles, (hipStream_t) stream);
+                                                    capacity_tiles, nullptr, 0, 0, (hipStream_t) stream);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "sparse assemble launch failed: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+extern "C" size_t rt_sparse_stamp_bytes(rt_ctx *ctx)
+{
+    if (!ctx) return 0;
+    const size_t max_tiles = (size_t) ((ctx->fa.width + 15u) / 16u) * ((ctx->max_local_rows + 15u) / 16u);
+    return sizeof(uint32_t) * (size_t) ctx->cfg.world * max_tiles;
+}
+
+extern "C" int rt_assemble_sparse_incremental(rt_ctx *ctx, const void *gathered, uint32_t capacity_tiles, void *full, void *stamps, uint32_t frame_tag,
+                                              void *stream)
+{
+    if (!ctx || !gathered || !full || !stamps) return fail(RT_ERR_INVALID, "rt_assemble_sparse_incremental: null argument");
+    if (ctx->cfg.format != RT_FMT_RGBA8) return fail(RT_ERR_INVALID, "rt_assemble_sparse_incremental: the context does not render RGBA8");
+    const uint32_t max_tiles = ((ctx->fa.width + 15u) / 16u) * ((ctx->max_local_rows + 15u) / 16u);
+    hipError_t e = rt_launch_assemble_sparse_strict(gathered, full, ctx->fa.width, ctx->fa.height, ctx->cfg.world, ctx->cfg.band_rows, bg_rgba8(ctx->fa),
+                                                    capacity_tiles, stamps, max_tiles, frame_tag, (hipStream_t) stream);
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "sparse assemble launch failed: %s", hipGetErrorString(e));
     return RT_OK;
 }

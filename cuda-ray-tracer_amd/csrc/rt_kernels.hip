@@ -261,9 +261,40 @@ __global__ __launch_bounds__(256) void fill_kernel(uint32_t *__restrict__ full, 
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) full[i] = bg;
 }
 
+// Incremental reassembly: the frame buffer keeps what earlier frames scattered into it, so only tiles that an EARLIER
+// frame delivered and this one did not have to go back to the background.  stamps[r][t] = tag of the last frame that
+// delivered tile t of rank r (0 = the tile is background in the buffer).  One wave per 64 (rank, tile) entries looks;
+// a stale entry is repainted by its whole wave, one 16-byte piece per lane (rare: the camera moved away from it).
+__global__ __launch_bounds__(64) void clear_stale_kernel(uint32_t *__restrict__ full, uint32_t *__restrict__ stamps, uint32_t width, uint32_t height,
+                                                         uint32_t world, uint32_t band_rows, uint32_t tiles_x, uint32_t max_tiles, uint32_t tag, uint32_t bg)
+{
+    const uint32_t lane = threadIdx.x;
+    const size_t e = (size_t) blockIdx.x * 64u + lane, n = (size_t) world * max_tiles;
+    uint32_t st = 0;
+    if (e < n) st = stamps[e];
+    unsigned long long stale = __ballot(st != 0u && st != tag);
+    if (st != 0u && st != tag) stamps[e] = 0u;
+    while (stale) { // wave-uniform
+        const uint32_t l = (uint32_t) __builtin_ctzll(stale);
+        stale &= stale - 1ull;
+        const size_t es = (size_t) blockIdx.x * 64u + l;
+        const uint32_t r = (uint32_t) (es / max_tiles), tile = (uint32_t) (es - (size_t) r * max_tiles);
+        const uint32_t x = (tile % tiles_x) * 16u + (lane & 3u) * 4u, lr = (tile / tiles_x) * 16u + (lane >> 2);
+        const uint32_t b = lr / band_rows;
+        const uint64_t y = ((uint64_t) b * world + r) * band_rows + (lr - b * band_rows);
+        if (y >= height) continue;
+        uint32_t *row = full + (size_t) y * width;
+        if (x < width) row[x] = bg;
+        if (x + 1u < width) row[x + 1u] = bg;
+        if (x + 2u < width) row[x + 2u] = bg;
+        if (x + 3u < width) row[x + 3u] = bg;
+    }
+}
+
 // root: tile j of rank r's message goes back to its pixels of the full frame (band-cyclic rows, like assemble_kernel)
 __global__ __launch_bounds__(64) void scatter_sparse_kernel(const uint32_t *__restrict__ gathered, uint32_t *__restrict__ full, uint32_t width,
-                                                            uint32_t height, uint32_t world, uint32_t band_rows, uint32_t tiles_x, uint32_t cap)
+                                                            uint32_t height, uint32_t world, uint32_t band_rows, uint32_t tiles_x, uint32_t cap,
+                                                            uint32_t *__restrict__ stamps, uint32_t max_tiles, uint32_t tag)
 {
     const uint32_t r = blockIdx.x / cap, j = blockIdx.x - r * cap, lane = threadIdx.x;
     const uint32_t off_tiles = (4u + cap + 3u) & ~3u;
@@ -272,6 +303,7 @@ __global__ __launch_bounds__(64) void scatter_sparse_kernel(const uint32_t *__re
     const uint32_t count = msg[0] < cap ? msg[0] : cap;
     if (j >= count) return;
     const uint32_t tile = msg[4u + j];
+    if (stamps && lane == 0 && tile < max_tiles) stamps[(size_t) r * max_tiles + tile] = tag; // this frame delivered the tile
     const uint4 v = reinterpret_cast<const uint4 *>(msg + off_tiles)[(size_t) j * 64u + lane];
     const uint32_t x = (tile % tiles_x) * 16u + (lane & 3u) * 4u, lr = (tile / tiles_x) * 16u + (lane >> 2);
     const uint32_t b = lr / band_rows;
@@ -339,16 +371,32 @@ extern "C" hipError_t RT_SYM(rt_launch_pack_sparse)(const void *fb, void *msg, u
     return hipGetLastError();
 }
 
+// stamps == NULL: stateless (fill everything, scatter).  stamps != NULL: incremental -- `full` and `stamps` carry over from
+// the previous call on this buffer (tag 0 = first call: fill everything and clear the stamps), max_tiles entries per rank.
 extern "C" hipError_t RT_SYM(rt_launch_assemble_sparse)(const void *gathered, void *full, uint32_t width, uint32_t height, uint32_t world,
-                                                         uint32_t band_rows, uint32_t bg, uint32_t cap, hipStream_t stream)
+                                                         uint32_t band_rows, uint32_t bg, uint32_t cap, void *stamps, uint32_t max_tiles, uint32_t tag,
+                                                         hipStream_t stream)
 {
     using namespace RT_SYM(rtk);
     const size_t n = (size_t) width * height;
     if (n == 0) return hipSuccess;
-    const uint32_t blocks = (uint32_t) ((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, stream, (uint32_t *) full, n, bg);
+    const uint32_t tiles_x = (width + 15u) / 16u;
+    if (!stamps || tag == 0u) {
+        const uint32_t blocks = (uint32_t) ((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+        hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, stream, (uint32_t *) full, n, bg);
+        if (stamps) {
+            hipError_t e = hipMemsetAsync(stamps, 0, sizeof(uint32_t) * (size_t) world * max_tiles, stream);
+            if (e != hipSuccess) return e;
+        }
+    }
+    const uint32_t use_tag = tag == 0u ? 0xFFFFFFFFu : tag; // the first call stamps with a value no later call may use
     if (cap != 0u && world != 0u)
         hipLaunchKernelGGL(scatter_sparse_kernel, dim3(world * cap), dim3(64), 0, stream, (const uint32_t *) gathered, (uint32_t *) full, width, height,
-                           world, band_rows, (width + 15u) / 16u, cap);
+                           world, band_rows, tiles_x, cap, (uint32_t *) stamps, max_tiles, use_tag);
+    if (stamps && tag != 0u && world != 0u && max_tiles != 0u) {
+        const size_t entries = (size_t) world * max_tiles;
+        hipLaunchKernelGGL(clear_stale_kernel, dim3((uint32_t) ((entries + 63) / 64)), dim3(64), 0, stream, (uint32_t *) full, (uint32_t *) stamps, width,
+                           height, world, band_rows, tiles_x, max_tiles, use_tag, bg);
+    }
     return hipGetLastError();
 }

@@ -180,6 +180,14 @@ size_t rt_sparse_bytes(uint32_t capacity_tiles);
 int rt_render_sparse(rt_ctx *ctx, const double cam[16], void *dev_msg, uint32_t capacity_tiles, void *stream, float *ms);
 int rt_pack_sparse(rt_ctx *ctx, const void *dev_fb, void *dev_msg, uint32_t capacity_tiles, void *stream);
 int rt_assemble_sparse(rt_ctx *ctx, const void *gathered_msgs, uint32_t capacity_tiles, void *full, void *stream);
+/* The same without repainting the whole frame every time: `full` and `stamps` (rt_sparse_stamp_bytes(ctx) bytes of device
+ * memory owned by the caller, one pair per output buffer) carry over from the previous call on that buffer; only tiles an
+ * earlier frame delivered and this one did not are painted back to the background.  frame_tag: 0 on the first call for a
+ * buffer (paints everything, clears the stamps), afterwards any value in [1, 0xFFFFFFFE] that differs from the previous
+ * call's. */
+size_t rt_sparse_stamp_bytes(rt_ctx *ctx);
+int rt_assemble_sparse_incremental(rt_ctx *ctx, const void *gathered_msgs, uint32_t capacity_tiles, void *full, void *stamps, uint32_t frame_tag,
+                                   void *stream);
 
 /* Counters of the last render done with RT_FLAG_COUNT. */
 int rt_get_counters(rt_ctx *ctx, rt_counters *out);

@@ -668,3 +668,33 @@ def test_render_sparse_equals_render_plus_pack(pkg, w, h, world, band, name):
                 assert np.array_equal(out.cpu().numpy(), want), (cap, frame)
         if cap == n_tiles:
             assert not overflowed.any()
+
+
+def test_incremental_sparse_assembly_follows_a_moving_camera(pkg):
+    """rt_assemble_sparse_incremental keeps the frame buffer between frames and only repaints tiles that lost their content:
+    cut between views (content appears, moves, disappears entirely, comes back) and compare every frame with the dense
+    single-context frame."""
+    import torch
+    w, h, world, band = 400, 300, 3, 16
+    sc = random_scene(pkg, 777, 9, 4, w=w, h=h, with_plane=False)
+    sc2 = sc  # same scene for the RGBA8 contexts
+    ref = pkg.Renderer(sc, device=0, fmt=pkg.RT_FMT_RGBA8)
+    rs = [pkg.Renderer(sc2, device=0, rank=r, world=world, band_rows=band, fmt=pkg.RT_FMT_RGBA8) for r in range(world)]
+    cap = max(((w + 15) // 16) * ((ren.local_rows + 15) // 16) for ren in rs)
+    nbytes = pkg.Renderer.sparse_bytes(cap)
+    msgs = torch.zeros((world, nbytes), dtype=torch.uint8, device="cuda:0")
+    full = torch.full((h, w, 4), 3, dtype=torch.uint8, device="cuda:0")
+    stamps = torch.full((rs[0].sparse_stamp_bytes(),), 0x5A, dtype=torch.uint8, device="cuda:0")   # garbage: tag 0 must clear it
+    cams = [pkg.camera_matrix((0.0, 0.0, 0.0), 90.0, 0.0), pkg.camera_matrix((2.0, 0.5, 1.0), 80.0, 3.0), pkg.camera_matrix((0.0, 0.0, 0.0), -90.0, 0.0),
+            pkg.camera_matrix((0.0, 0.0, 0.0), -90.0, 0.0), pkg.camera_matrix((-3.0, 1.0, 4.0), 100.0, -5.0), pkg.camera_matrix((0.0, 0.0, 0.0), 90.0, 0.0)]
+    saw_content = 0
+    for k, cam in enumerate(cams):
+        for r, ren in enumerate(rs):
+            ren.update_sparse(msgs[r].data_ptr(), cap, cam)
+        rs[0].assemble_sparse_incremental(msgs.data_ptr(), cap, full.data_ptr(), stamps.data_ptr(), k)   # tag 0 first, then 1, 2, ...
+        ref.update(cam)
+        torch.cuda.synchronize()
+        want = ref.download()
+        assert np.array_equal(full.cpu().numpy(), want), f"frame {k}"
+        saw_content += int(msgs.cpu().numpy().view(np.uint32)[:, 0].sum() > 0)
+    assert 3 <= saw_content < len(cams)   # the sequence really has frames with and without content

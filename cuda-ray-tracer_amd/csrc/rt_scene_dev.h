@@ -128,6 +128,6 @@ struct FrameArgs {
 
 #define RT_TILE 16        // a workgroup renders a 16 x 16 pixel tile
 #define RT_ORD_HDR 16      // words before word[] in one generation of FrameArgs::order_state
-#define RT_ORD_MAX_TILES 16384u // larger launches are many workgroups per slot deep: the order stops mattering
+#define RT_ORD_MAX_TILES 262144u // 8K frames (129 600 tiles) included: the order still pays there (measured), the state is 20 B per tile and generation
 
 #endif

@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     // n_tiles slots are the tiles in index order, and the ones a list slot covers exit at once.  Every tile is
     // rendered exactly once whatever the lists and ord_cap say, so they change the time, never the image.
     //
-    // This pays when few tiles have hits and the launch is only a few workgroups per slot deep (config 2: 15 % of 8160
+    // This pays most when few tiles have hits and the launch is only a few workgroups per slot deep (config 2: 15 % of 8160
     // tiles, -7 %); otherwise it costs a dependent load at the start of every workgroup and one same-address device
     // atomic per tile with hits (those sustain ~90 per microsecond): +5 % on a frame where every tile has hits.  So
     // one tile in 16 takes part in a census, the host sees it through a mapped word and switches the ordering off

@@ -293,7 +293,7 @@ def main():
 
     # outside the timed region: the reassembled N-rank frame must equal a single-context render of the same scene
     frame_check = None
-    if world > 1 and rank == 0 and W * H <= 3840 * 2160:
+    if world > 1 and rank == 0 and W * H <= 7680 * 4320:
         ref = pkg.Renderer(scene, device=local_rank, flags=flags, fmt=fmt)
         ref.update(cam)
         last = (state["k"] - 1) & 1
@@ -337,13 +337,13 @@ def main():
         }
         if frame_check is not None:
             result["config"]["gathered_frame_identical_to_single_gpu_frame"] = frame_check
-            if sparse:
-                hdr = gathered_msg[(state["k"] - 1) & 1][:, :8].cpu().numpy().view(np.uint32)
-                result["config"]["gather"] = {"kind": "sparse tiles", "capacity_tiles_per_rank": cap, "bytes_per_rank": msg_bytes,
-                                              "dense_bytes_per_rank": int(mx * W * px_bytes), "tiles_sent_per_rank": [int(v) for v in hdr[:, 0]],
-                                              "overflow": bool(hdr[:, 1].any())}
-            else:
-                result["config"]["gather"] = {"kind": "dense rows", "bytes_per_rank": int(mx * W * px_bytes)}
+        if world > 1 and sparse:
+            hdr = gathered_msg[(state["k"] - 1) & 1][:, :8].cpu().numpy().view(np.uint32)
+            result["config"]["gather"] = {"kind": "sparse tiles", "capacity_tiles_per_rank": cap, "bytes_per_rank": msg_bytes,
+                                          "dense_bytes_per_rank": int(mx * W * px_bytes), "tiles_sent_per_rank": [int(v) for v in hdr[:, 0]],
+                                          "overflow": bool(hdr[:, 1].any())}
+        elif world > 1:
+            result["config"]["gather"] = {"kind": "dense rows", "bytes_per_rank": int(mx * W * px_bytes)}
         if not args.no_cpu_baseline and world == 1:
             O = graft.load_oracle()
             osc = O.load_scene(os.path.join(ROOT, "scenes", scene_name + ".yml")).with_size(W, H, max_refl)

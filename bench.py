@@ -1,39 +1,79 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the per-pixel ray-tracing hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: this process only starts N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one frame: every pixel's primary ray, nearest hit over all surfaces, shadow rays to all lights,
-Lambert shading and the mirror-bounce loop, written to an RGBA32F framebuffer resident in HBM.
+Lambert shading and the mirror-bounce loop, written to a framebuffer resident in HBM.
 Metric (BASELINE.json): Mrays/s on scenes/20spheres.yml; a ray = one primary, shadow or reflection ray
 (SURVEY.md 8(d)); rays per frame are counted by the kernel itself (RT_FLAG_COUNT pass before timing).
 
-N = 1: BASELINE config 2, 20spheres @ 1920x1080, camera = identity (the reference host's start-up pose).
+N = 1: BASELINE config 2, 20spheres @ 1920x1080, camera = identity (the reference host's start-up pose), RGBA32F.
 N > 1: weak scaling -- the same scene at N x the pixels (same 16:9 aspect), rows band-cyclic over the ranks
-(no data-path communication while rendering), one RCCL gather of the tiles to rank 0 per frame + a device
-reassembly kernel on rank 0, as BASELINE.json's north_star prescribes.
+(no data-path communication while rendering), one RCCL gather to rank 0 per frame + a device reassembly kernel on
+rank 0, as BASELINE.json's north_star prescribes.  The headline `value` is measured on the SAME output as N = 1
+(RGBA32F, dense rows); the RGBA8 / sparse-tile transport is timed in a second region and reported as `config.alt`.
 
-Prints ONE JSON line (rank 0).  The oracle (oracle/) is used ONLY for the `cpu_baseline` leg.
+Prints ONE JSON line (rank 0).  The oracle (oracle/) is used ONLY for the `cpu_baseline` legs.
 """
 import argparse
+import hashlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import __graft_entry__ as graft  # noqa: E402
 
-FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz = half the FP32 vector
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 FP64 lanes/clk x 2 flop x 2.4 GHz = half the FP32 vector
                                  # peak (157.3 TF, MI355X_MICROARCH.md chip table); checked by profiles/*fp64_peak*
 HBM_PEAK_GBS = 8000.0
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.txt")
+KERNEL_SOURCES = ["cuda-ray-tracer_amd/csrc/rt_wavefront.hip", "cuda-ray-tracer_amd/csrc/rt_math.hpp",
+                  "cuda-ray-tracer_amd/csrc/rt_scene_dev.h", "cuda-ray-tracer_amd/csrc/rt_wavefront_math.hpp"]
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# --gpus N > 1 without a launcher: start the N rank processes ourselves
+# ----------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    """Start N fresh copies of this script, one per GPU, BEFORE anything in this process imports torch or touches HIP
+    (the parent stays a plain supervisor: no exec of a GPU-initialised process, no fork of one).  Rank 0's JSON line goes
+    to our stdout; any rank failing makes the whole run fail."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank process {p.pid} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for q in live:   # exactly the processes started above
+                    q.terminate()
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# workloads
+# ----------------------------------------------------------------------------------------------------------------
 def workload_for(n_gpus, name):
     if name == "config5":
         return "20spheres", 7680, 4320, None
@@ -41,56 +81,121 @@ def workload_for(n_gpus, name):
         return "reflection_test", 1920, 1080, 4
     if name == "config4":
         return "clebsch", 3840, 2160, None
+    if name == "config1":
+        return "quadratic", 640, 480, None
     s = math.sqrt(n_gpus)
     w = int(round(1920 * s / 16.0)) * 16
     h = int(round(w * 9 / 16.0))
     return "20spheres", w, h, None
 
 
-# FP64 operations per unit of work of the KERNEL'S OWN algorithm (strict build: every mul / add / sub / div / sqrt is
-# one separately rounded operation = 1 flop; DESIGN.md "Flop accounting" derives each figure from rt_wavefront.hip /
-# rt_math.hpp).  The reference's dense as-written count is 286 + solver per test; these are far
-# below it because absent coefficient groups, shared per-ray monomials, the primary-ray t0 table and culling remove
-# work -- which is why `achieved` must not be computed from the dense figure.
-FLOPS = {
-    "test_executed": {"unitsq": 16.0, "quadric": 50.0, "linear": 13.0, "cubic": 316.0},  # t2,t1,t0 + discriminant
-    "solve": 20.0,          # recompute t1,t0 (13) + delta (3) + sqrt + (-t1 -+ sqrt) + 2*t2 + division
-    "cull_eval": 40.0,      # one bounding-volume decision (relevant_mask / primary_cone_mask), one lane
-    "primary_ray": 66.0,    # pixel -> direction (45, incl. normalise) + monomials (21)
-    "shadow_ray": 14.0,     # FP32 round trip + mixed monomials; point lights also form d*d (same order)
-    "reflect_ray": 40.0,    # reflect + bias + full monomials
-    "hit": 100.0,           # point (6) + gradient normal (~80 on the 20-coefficient form) + shadow bias (6) + shading dots
-}
+def orbit_pose(pkg, i, n=24):
+    """Pose i of n on an orbit around the 20spheres scene (tools/flythrough_bench.py): the reference host's camera
+    (src/ray-tracer.cpp:44-58) looking at (5, 2, 15) from 14 units away."""
+    import numpy as np
+    a = 2.0 * np.pi * i / n
+    pos = (5.0 + 14.0 * np.sin(a), 2.0 + 2.0 * np.sin(2 * a), 15.0 - 14.0 * np.cos(a))
+    yaw = float(np.degrees(np.arctan2(15.0 - pos[2], 5.0 - pos[0])))
+    pitch = float(-np.degrees(np.arctan2(pos[1] - 2.0, 14.0)))
+    return pkg.camera_matrix(pos, yaw, pitch)
 
 
-def algorithmic_flops(cnt, classes):
-    """FP64 operations one frame of the wavefront kernel executes, from the kernel's own work counters."""
-    per_class = {"unitsq": "unitsq", "square": "quadric", "cross": "quadric", "linear": "linear", "cubic": "cubic"}
-    mix = sum(FLOPS["test_executed"][per_class[c]] for c in classes) / max(1, len(classes))
-    return (cnt["tests_executed"] * mix + cnt["solves"] * FLOPS["solve"] + cnt["cull_evals"] * FLOPS["cull_eval"] +
-            cnt["primary_rays"] * FLOPS["primary_ray"] + cnt["shadow_rays"] * FLOPS["shadow_ray"] +
-            cnt["reflect_rays"] * FLOPS["reflect_ray"] + cnt["hits"] * FLOPS["hit"])
+# ----------------------------------------------------------------------------------------------------------------
+# flop accounting (DESIGN.md section 6)
+# ----------------------------------------------------------------------------------------------------------------
+def load_flop_table():
+    """FP64 operations per unit of work of the KERNEL'S OWN algorithm.  The figures come from tools/count_flops.cpp, which
+    runs the kernel's math (rt_math.hpp, rt_wavefront_math.hpp -- the very headers the kernel is compiled from) over an
+    operation-counting scalar: the technique SURVEY.md 8(d) prescribes (add / sub / mul / div / sqrt = 1 each, strict build,
+    so no FMA).  The reference's dense as-written count is 286 + solver per test; these are far below it because absent
+    coefficient groups, shared per-ray monomials and culling remove work -- which is why `achieved` must not be computed
+    from the dense figure, and is capped by it."""
+    path = os.path.join(ROOT, "profiles", "flop_table.json")
+    with open(path) as fh:
+        return json.load(fh), os.path.relpath(path, ROOT)
 
 
-def pmc_traffic_bytes(args, world):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_final_pmc_summary.txt:
-    separate rocprofv3 --pmc runs of this same command; FETCH_SIZE / WRITE_SIZE are in KiB, FETCH_SIZE doubled as the
-    MI355X guide prescribes for gfx950).  Only valid for the default single-GPU workload the passes were taken on."""
-    if world != 1 or args.workload != "config2" or args.kernel != "wavefront" or args.mode != "strict" or args.format != "rgba32f":
+def dense_reference_flops(cnt):
+    """The reference's as-written FP64 count for the tests it would run: 286 per expansion + solver
+    (linear 1, quadratic miss 4 / hit 8, Cardano 26, trig 39), from the per-branch counters of the COUNT build."""
+    b = cnt.get("ref_branches")
+    if b:
+        return (286.0 * cnt["tests"] + 1.0 * b["linear"] + 4.0 * b["quad_miss"] + 8.0 * b["quad_hit"] + 26.0 * b["cardano"] + 39.0 * b["trig"]
+                + 79.0 * cnt["hits"])
+    return 290.0 * cnt["tests"] + 79.0 * cnt["hits"]
+
+
+def algorithmic_flops(cnt, table):
+    """FP64 operations one frame of the wavefront kernel executes: executed units (device counters, per surface class)
+    x the counted cost of each unit."""
+    u = table["units"]
+    ex = cnt["executed_by_class"]
+    so = cnt["solves_by_class"]
+    cu = cnt["cull_by_kind"]
+    f = 0.0
+    f += ex["unitsq"] * u["test_unitsq"] + ex["quadric"] * u["test_quadric"] + ex["linear"] * u["test_linear"] + ex["cubic"] * u["test_cubic_expand"]
+    f += so["unitsq"] * u["solve_quadratic"] + so["quadric"] * u["solve_quadratic"] + so["linear"] * u["solve_linear"]
+    cb = cnt["cubic_branches"]
+    f += cb["cardano"] * u["solve_cardano"] + cb["trig"] * u["solve_trig"] + cb["quad"] * u["solve_quadratic"] + cb["linear"] * u["solve_linear"]
+    f += cu["tile"] * u["cull_tile"] + cu["primary"] * u["cull_primary"] + cu["shadow"] * u["cull_shadow"]
+    f += cnt["primary_rays"] * u["primary_ray"] + cnt["shadow_rays"] * u["shadow_ray"] + cnt["reflect_rays"] * u["reflect_ray"]
+    f += cnt["hits"] * u["hit"]
+    return f
+
+
+def kernel_source_digest():
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        p = os.path.join(ROOT, rel)
+        if os.path.exists(p):
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(args, world):
+    """Counters of the dominant kernel from the committed PMC passes (separate `rocprofv3 --pmc` runs of this same command,
+    tools/pmc_profile.sh; FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled as the MI355X guide prescribes for gfx950).
+    NOT measured by this run: the source is named in the JSON line, and the figures are dropped when the kernel sources
+    have changed since the passes were taken or when this is not the workload they were taken on."""
+    if world != 1 or args.workload != "config2" or args.kernel != "wavefront" or args.mode != "strict" or args.format != "rgba32f" or args.camera != "static":
         return None
-    path = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.txt")
+    path = os.path.join(ROOT, PMC_SUMMARY)
     try:
-        vals = {}
+        vals, digest = {}, None
         for line in open(path):
             f = line.split()
-            if len(f) >= 3 and f[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+            if len(f) >= 3 and f[0] == "#" and f[1] == "kernel_source_digest":
+                digest = f[2]
+            elif len(f) >= 3 and f[1] == "mean":
                 vals[f[0]] = float(f[2])
-        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        if digest != kernel_source_digest():
+            return {"source": PMC_SUMMARY, "stale": True}
+        out = {"source": PMC_SUMMARY, "stale": False}
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            out["traffic"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        need = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU")
+        if all(k in vals for k in need):
+            # FP64 wave-instructions x 64 lanes x the fraction of lanes active per VALU instruction.
+            # SQ_THREAD_CYCLES_VALU counts active lanes x quad-cycles; an instruction of a full wave takes one quad-cycle
+            # for 64 lanes, so lanes-per-instruction = THREAD_CYCLES / INSTS and the active fraction is that / 64.
+            active = min(1.0, vals["SQ_THREAD_CYCLES_VALU"] / vals["SQ_INSTS_VALU"] / 64.0)
+            slots = (vals["SQ_INSTS_VALU_ADD_F64"] + vals["SQ_INSTS_VALU_MUL_F64"] + 2.0 * vals["SQ_INSTS_VALU_FMA_F64"]) * 64.0
+            out["fp64_lane_slots"] = slots
+            out["active_lane_fraction"] = active
+            out["flops"] = slots * active
+        if "SQ_ACTIVE_INST_VALU" in vals and "SQ_BUSY_CYCLES" in vals and "GRBM_GUI_ACTIVE" in vals:
+            # VALU busy: SQ_ACTIVE_INST_VALU is in quad-cycles summed over all waves; GRBM_GUI_ACTIVE is the sum of the 8 XCDs'
+            # active cycles -> kernel cycles = GRBM / 8; SIMD-cycles available = kernel cycles x 256 CUs x 4 SIMDs
+            kernel_cycles = vals["GRBM_GUI_ACTIVE"] / 8.0
+            out["valu_busy"] = vals["SQ_ACTIVE_INST_VALU"] * 4.0 / (kernel_cycles * 1024.0)
+            out["valu_busy_formula"] = "SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)"
+        return out
     except Exception:
         return None
 
 
 def object_classes(arr):
+    import numpy as np
     out = []
     for c in arr["coefs"]:
         if np.any(c[:10] != 0):
@@ -106,52 +211,272 @@ def object_classes(arr):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="config2", help="config2 (default, weak-scaled with --gpus) | config3 | config4 | config5")
-    ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
-    ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "wavefront-nocull", "simple"],
-                    help="A/B switch; the product default is the culling wavefront kernel")
-    ap.add_argument("--band-rows", type=int, default=16)
-    ap.add_argument("--format", default="auto", choices=["auto", "rgba32f", "rgba8"],
-                    help="framebuffer / wire format.  rgba32f = the CPU back end's un-quantised floats (the parity format; "
-                         "default on one GPU).  rgba8 = iround(c*255) RGBA8, the format the reference's CUDA back end writes "
-                         "(src/update-cuda.cu:149-156); default when the frame is gathered (N > 1): the gather to rank 0 is "
-                         "xGMI-bound and a float frame is 4x the bytes of the frame a display needs")
-    ap.add_argument("--gather", default="sparse", choices=["sparse", "dense"],
-                    help="what a rank sends to rank 0 (N > 1, rgba8).  dense = its rows; sparse = only its 16x16 tiles that are not "
-                         "pure background, with their ids, in a fixed-size message (rt_render_sparse / rt_assemble_sparse): the gather "
-                         "is xGMI-bound and 83 %% of this workload's tiles are background")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL (the product path). gloo stages the gather through host memory and lets several ranks share "
-                         "one GPU: only for rehearsing the N>1 code path on a 1-GPU box")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
-    args = ap.parse_args()
+# ----------------------------------------------------------------------------------------------------------------
+# one wire format of the N-rank frame: what every rank renders into, what travels, how rank 0 rebuilds the frame
+# ----------------------------------------------------------------------------------------------------------------
+class FramePath:
+    """Render -> (gather -> reassemble) for one framebuffer format.  Pipelined over two buffer sets on ONE stream per rank: the
+    gather of frame k travels while frame k+1 renders, and rank 0 reassembles frame k behind its own render of frame k+1."""
 
+    def __init__(self, env, fmt_name, gather_kind, cams):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        self.np, self.torch, self.dist = np, torch, dist
+        self.env, self.fmt_name, self.cams = env, fmt_name, cams
+        pkg, args = env["pkg"], env["args"]
+        self.pkg = pkg
+        self.world, self.rank, self.dev, self.W, self.H = env["world"], env["rank"], env["dev"], env["W"], env["H"]
+        self.dist_on, self.nccl = env["dist_on"], args.backend == "nccl"
+        self.root = self.rank == 0
+        self.fmt = pkg.RT_FMT_RGBA8 if fmt_name == "rgba8" else pkg.RT_FMT_RGBA32F
+        self.px_dtype, self.px_bytes = (torch.uint8, 4) if fmt_name == "rgba8" else (torch.float32, 16)
+        self.ren = pkg.Renderer(env["scene"], device=env["local_rank"], rank=self.rank, world=self.world, band_rows=args.band_rows, flags=env["flags"], fmt=self.fmt)
+        self.mx = self.ren.max_local_rows
+        self.stream = torch.cuda.current_stream(self.dev)
+        W, H, dev, world = self.W, self.H, self.dev, self.world
+        nb = 2 if self.dist_on else 1
+        self.sparse = self.dist_on and gather_kind == "sparse" and fmt_name == "rgba8"
+        self.local = [torch.empty((self.mx, W, 4), dtype=self.px_dtype, device=dev) for _ in range(nb)]
+        self.gathered = [torch.empty((world, self.mx, W, 4), dtype=self.px_dtype, device=dev) for _ in range(2)] if (self.root and self.dist_on) else None
+        self.full = [torch.empty((H, W, 4), dtype=self.px_dtype, device=dev) for _ in range(2)] if (self.root and self.dist_on) else None
+        self.works = [None, None]
+        self.k = 0
+        self.kernel_events = []       # (start, end) pairs around the render launches of the timed region
+        self.record_kernel_events = False
+        self.dense_resends = 0
+        self.overflow_frames = []
+        self.pending_hdr = []         # sparse: (frame k, buffer b, pinned header copy, event) not yet inspected
+        self.cap = self.msg_bytes = 0
+        if self.sparse:
+            self._init_sparse()
+
+    # sparse gather: capacity = tiles with content of the busiest rank (one untimed frame) + 25 % + 64, same on every rank
+    def _init_sparse(self):
+        np, torch, dist, pkg, ren = self.np, self.torch, self.dist, self.pkg, self.ren
+        my_tiles = ((self.W + 15) // 16) * ((ren.local_rows + 15) // 16)
+        probe = torch.zeros(pkg.Renderer.sparse_bytes(max(my_tiles, 1)), dtype=torch.uint8, device=self.dev)
+        ren.update_sparse(probe.data_ptr(), max(my_tiles, 1), self.cams[0], stream=self.stream.cuda_stream, timed=False)
+        torch.cuda.synchronize()
+        need = torch.tensor([int(probe[:4].cpu().numpy().view(np.uint32)[0]), my_tiles], dtype=torch.int64, device=self.env["cdev"])
+        dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        self.cap = int(min(int(need[1]), int(need[0]) + int(need[0]) // 4 + 64)) if not self.env["args"].sparse_capacity else self.env["args"].sparse_capacity
+        self.msg_bytes = pkg.Renderer.sparse_bytes(self.cap)
+        self.msg = [torch.zeros(self.msg_bytes, dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        self.gathered_msg = [torch.zeros((self.world, self.msg_bytes), dtype=torch.uint8, device=self.dev) for _ in range(2)] if self.root else None
+        self.stamps = [torch.zeros(ren.sparse_stamp_bytes(), dtype=torch.uint8, device=self.dev) for _ in range(2)] if self.root else None
+        self.asm_tag = [0, 0]   # per output buffer: 0 = first reassembly (paints everything), then 1, 2, ...
+        self.hdr_host = [torch.zeros((self.world, 8), dtype=torch.uint8).pin_memory() for _ in range(2)] if self.root else None
+
+    def cam_of(self, k):
+        return self.cams[k % len(self.cams)]
+
+    def _gather(self, send, recv):
+        """The one collective of the path.  RCCL: async, the next frame's render is enqueued behind this call without waiting
+        for it (it starts after the work already on this stream, so rank 0's reassembly of frame k-2 out of the same receive
+        buffer is finished by then).  gloo (rehearsal only): staged through host memory."""
+        dist, torch = self.dist, self.torch
+        if self.nccl:
+            return dist.gather(send, list(recv.unbind(0)) if self.root else None, dst=0, async_op=True)
+        lc = send.cpu()
+        gl = [torch.empty_like(lc) for _ in range(self.world)] if self.root else None
+        w = dist.gather(lc, gl, dst=0, async_op=True)
+        w.wait()
+        if self.root:
+            recv.copy_(torch.stack(gl))
+        return w
+
+    def _assemble(self, b):
+        """root: turn what gather b delivered into the full frame b (same stream: no side stream, no events)."""
+        if self.nccl:
+            self.works[b].wait()   # stream-side: the render stream waits for the collective, the host does not
+        if self.sparse:   # incremental: each output buffer keeps its frame, only tiles that lost their content are repainted
+            self.ren.assemble_sparse_incremental(self.gathered_msg[b].data_ptr(), self.cap, self.full[b].data_ptr(), self.stamps[b].data_ptr(), self.asm_tag[b],
+                                                 stream=self.stream.cuda_stream)
+            self.asm_tag[b] = 1 if self.asm_tag[b] >= 0xFFFFFFF0 else self.asm_tag[b] + 1
+        else:
+            self.ren.assemble(self.gathered[b].data_ptr(), self.full[b].data_ptr(), stream=self.stream.cuda_stream)
+
+    def _render(self, cam, b):
+        torch = self.torch
+        ev = None
+        if self.record_kernel_events:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(self.stream)
+        if self.sparse:   # the kernel writes this rank's tiles with hits straight into the fixed-size message
+            self.ren.update_sparse(self.msg[b].data_ptr(), self.cap, cam, stream=self.stream.cuda_stream, timed=False)
+        else:
+            self.ren.update(cam, dev_fb=self.local[b].data_ptr(), stream=self.stream.cuda_stream, timed=False)
+        if ev:
+            ev[1].record(self.stream)
+            self.kernel_events.append(ev)
+
+    def step(self):
+        """One frame per rank."""
+        k = self.k
+        self.k = k + 1
+        cam = self.cam_of(k)
+        if not self.dist_on:
+            self._render(cam, 0)
+            return
+        b = k & 1
+        if self.works[b] is not None:
+            self.works[b].wait()   # frame k-2 has left its send buffer (stream-side wait for RCCL, already complete for gloo)
+        self._render(cam, b)
+        if self.sparse:
+            self.works[b] = self._gather(self.msg[b], self.gathered_msg[b] if self.root else None)
+        else:
+            self.works[b] = self._gather(self.local[b], self.gathered[b] if self.root else None)
+        if self.root and k >= 1:
+            self._finish_frame(k - 1)   # the previous frame: its gather had a whole render to arrive
+
+    def _finish_frame(self, k):
+        b = k & 1
+        self._assemble(b)
+        if self.sparse:
+            # Did any rank's message overflow?  The headers are copied to pinned memory behind the reassembly and looked at
+            # when the copy has landed (no host wait in the pipeline); an overflowed frame is sent again densely (below).
+            torch = self.torch
+            self.hdr_host[b].copy_(self.gathered_msg[b][:, :8].contiguous(), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self.pending_hdr.append((k, b, ev))
+            self._poll_overflow(block=False)
+
+    def _poll_overflow(self, block):
+        np = self.np
+        keep = []
+        for (k, b, ev) in self.pending_hdr:
+            if block:
+                ev.synchronize()
+            if ev.query():
+                if self.hdr_host[b].numpy().view(np.uint32)[:, 1].any():
+                    self.overflow_frames.append(k)
+            else:
+                keep.append((k, b, ev))
+        self.pending_hdr = keep
+
+    def resend_dense(self, k):
+        """A sparse frame whose message overflowed on some rank: every rank renders frame k again into a dense RGBA8 buffer and
+        the rows are gathered and reassembled the general way (include/mi355rt.h: "send the dense frame instead").  Collective:
+        all ranks must call it for the same k, which they learn from rank 0 (see run_timed)."""
+        b = k & 1
+        self.ren.update(self.cam_of(k), dev_fb=self.local[b].data_ptr(), stream=self.stream.cuda_stream, timed=False)
+        w = self._gather(self.local[b], self.gathered[b] if self.root else None)
+        if self.nccl:
+            w.wait()   # stream-side
+        if self.root:
+            self.ren.assemble(self.gathered[b].data_ptr(), self.full[b].data_ptr(), stream=self.stream.cuda_stream)
+            self.asm_tag[b] = 0   # the incremental state of this output buffer no longer matches it: repaint next time
+        self.dense_resends += 1
+
+    def flush(self):
+        """root: reassemble the last frame (inside the timed region: K steps deliver K full frames); every rank: resend the
+        frames whose sparse message overflowed."""
+        if not self.dist_on:
+            return
+        if self.root and self.k >= 1:
+            self._finish_frame(self.k - 1)
+        if self.sparse:
+            torch, dist = self.torch, self.dist
+            if self.root:
+                self._poll_overflow(block=True)
+            n = torch.tensor([len(self.overflow_frames) if self.root else 0], dtype=torch.int64, device=self.env["cdev"])
+            dist.broadcast(n, src=0)
+            if int(n.item()):
+                ks = torch.tensor(self.overflow_frames if self.root else [0] * int(n.item()), dtype=torch.int64, device=self.env["cdev"])
+                dist.broadcast(ks, src=0)
+                for k in ks.tolist():
+                    self.resend_dense(int(k))
+            self.overflow_frames = []
+
+    def run_timed(self, steps, warmup):
+        """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; returns (max-over-ranks seconds, mean
+        kernel ms from HIP events on the render stream inside the timed region)."""
+        torch, dist = self.torch, self.dist
+        self.overflow_frames = []
+        for _ in range(warmup):
+            self.step()
+        self.flush()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.record_kernel_events = self.dist_on   # N = 1: the timed region is K back-to-back launches, one event pair suffices
+        self.kernel_events = []
+        if self.dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(self.stream)
+        for _ in range(steps):
+            self.step()
+        self.flush()
+        ev1.record(self.stream)
+        torch.cuda.synchronize()
+        if self.dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        self.record_kernel_events = False
+        tmax = torch.tensor([dt], dtype=torch.float64, device=self.env["cdev"])
+        if self.dist_on:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        if self.kernel_events:
+            kernel_ms = float(sum(a.elapsed_time(b) for a, b in self.kernel_events) / len(self.kernel_events))
+        else:
+            kernel_ms = ev0.elapsed_time(ev1) / steps
+        return float(tmax.item()), kernel_ms
+
+    def frame_check(self):
+        """Outside the timed region: the reassembled N-rank frame must equal a single-context render of the same scene."""
+        if not (self.dist_on and self.root) or self.W * self.H > 7680 * 4320:
+            return None
+        np = self.np
+        ref = self.pkg.Renderer(self.env["scene"], device=self.env["local_rank"], flags=self.env["flags"], fmt=self.fmt)
+        ref.update(self.cam_of(self.k - 1))
+        ok = bool(np.array_equal(ref.download(), self.full[(self.k - 1) & 1].cpu().numpy()))
+        ref.cleanup_update()
+        return ok
+
+    def gather_report(self):
+        np = self.np
+        if self.sparse:
+            hdr = self.gathered_msg[(self.k - 1) & 1][:, :8].cpu().numpy().view(np.uint32)
+            return {"kind": "sparse tiles", "capacity_tiles_per_rank": self.cap, "bytes_per_rank": self.msg_bytes, "dense_bytes_per_rank": int(self.mx * self.W * self.px_bytes),
+                    "tiles_sent_per_rank": [int(v) for v in hdr[:, 0]], "overflow_in_last_frame": bool(hdr[:, 1].any()), "frames_resent_densely": self.dense_resends}
+        return {"kind": "dense rows", "bytes_per_rank": int(self.mx * self.W * self.px_bytes)}
+
+    def close(self):
+        self.ren.cleanup_update()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def run_rank(args, world):
+    import numpy as np
     import torch
     import torch.distributed as dist
+    import __graft_entry__ as graft
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-tracing path has no CPU fallback")
+    ndev = torch.cuda.device_count()
     if args.backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()
+        local_rank = local_rank % ndev
+    elif local_rank >= ndev:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {ndev} GPU(s) (LOCAL_RANK {local_rank}); refusing to share a GPU between RCCL ranks")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collectives' tensors live
 
     pkg = graft.load_package()
@@ -161,206 +486,198 @@ def main():
         scene.set_max_reflections(max_refl)
     flags = pkg.RT_FLAG_FAST if args.mode == "fast" else pkg.RT_FLAG_STRICT
     flags |= {"wavefront": 0, "wavefront-nocull": pkg.RT_FLAG_NOCULL, "simple": pkg.RT_FLAG_SIMPLE}[args.kernel]
-    band = args.band_rows
-    cam = pkg.IDENTITY
+    if args.static_order:
+        flags |= pkg.RT_FLAG_STATIC_ORDER
     if args.format == "auto":
-        args.format = "rgba32f" if world == 1 else "rgba8"
-    fmt = pkg.RT_FMT_RGBA8 if args.format == "rgba8" else pkg.RT_FMT_RGBA32F
-    px_dtype, px_bytes = (torch.uint8, 4.0) if args.format == "rgba8" else (torch.float32, 16.0)
+        args.format = "rgba32f"
+    n_orbit = 24
+    cams = [orbit_pose(pkg, i, n_orbit) for i in range(n_orbit)] if args.camera == "orbit" else [pkg.IDENTITY]
+    env = dict(pkg=pkg, args=args, world=world, rank=rank, local_rank=local_rank, dev=dev, cdev=cdev, W=W, H=H, scene=scene, flags=flags, dist_on=dist_on)
 
-    # ---- ray accounting: one counting frame (not timed) ----
-    rc = pkg.Renderer(scene, device=local_rank, rank=rank, world=world, band_rows=band, flags=flags | pkg.RT_FLAG_COUNT, fmt=fmt)
-    rc.update(cam)
-    cnt = rc.counters()
-    rc.cleanup_update()
+    # ---- ray / work accounting: one counting frame per camera pose (not timed) ----
     keys = ["primary_rays", "shadow_rays", "reflect_rays", "tests", "hits", "solves", "tests_executed", "cull_evals"]
-    tot = torch.tensor([cnt[k] for k in keys], dtype=torch.int64, device=cdev)
-    if world > 1:
+    rc = pkg.Renderer(scene, device=local_rank, rank=rank, world=world, band_rows=args.band_rows, flags=flags | pkg.RT_FLAG_COUNT)
+    per_pose, detail0 = [], None
+    for cam in cams:
+        rc.update(cam)
+        c = rc.counters()
+        if detail0 is None:
+            detail0 = rc.counters_detail()
+        per_pose.append([c[k] for k in keys])
+    rc.cleanup_update()
+    tot = torch.tensor(per_pose, dtype=torch.int64, device=cdev)
+    if dist_on:
         dist.all_reduce(tot)
-    total = {k: int(v) for k, v in zip(keys, tot.tolist())}
-    rays_per_frame = total["primary_rays"] + total["shadow_rays"] + total["reflect_rays"]
+    tot = tot.cpu().numpy()
+    rays_per_pose = tot[:, 0] + tot[:, 1] + tot[:, 2]
+    total0 = {k: int(v) for k, v in zip(keys, tot[0])}
 
-    # ---- the timed path ----
-    ren = pkg.Renderer(scene, device=local_rank, rank=rank, world=world, band_rows=band, flags=flags, fmt=fmt)
-    mx = ren.max_local_rows
-    stream = torch.cuda.current_stream(dev)
-    root = rank == 0
-    # double-buffered so that the gather / reassembly of frame k overlaps the rendering of frame k+1 (N > 1)
-    local = [torch.empty((mx, W, 4), dtype=px_dtype, device=dev) for _ in range(2 if world > 1 else 1)]
-    gathered = [torch.empty((world, mx, W, 4), dtype=px_dtype, device=dev) for _ in range(2)] if (root and world > 1) else None
-    full = [torch.empty((H, W, 4), dtype=px_dtype, device=dev) for _ in range(2)] if (root and world > 1) else None
-    works = [None, None]
-    state = {"k": 0}
+    def rays_in(steps, warmup):  # rays of the timed frames (the orbit cycles through its poses, continuing after the warm-up)
+        return int(sum(int(rays_per_pose[(warmup + i) % len(cams)]) for i in range(steps)))
 
-    # sparse gather: capacity = tiles with content of the busiest rank (one untimed frame) + 25 % + 64, same on every rank
-    sparse = world > 1 and args.gather == "sparse" and args.format == "rgba8"
-    cap = msg_bytes = 0
-    msg = gathered_msg = stamps = asm_tag = None
-    if sparse:
-        my_tiles = ((W + 15) // 16) * ((ren.local_rows + 15) // 16)
-        probe = torch.zeros(pkg.Renderer.sparse_bytes(max(my_tiles, 1)), dtype=torch.uint8, device=dev)
-        ren.update_sparse(probe.data_ptr(), max(my_tiles, 1), cam, stream=stream.cuda_stream, timed=False)
-        torch.cuda.synchronize()
-        need = torch.tensor([int(probe[:4].cpu().numpy().view(np.uint32)[0]), my_tiles], dtype=torch.int64, device=cdev)
-        dist.all_reduce(need, op=dist.ReduceOp.MAX)
-        cap = int(min(int(need[1]), int(need[0]) + int(need[0]) // 4 + 64))
-        msg_bytes = pkg.Renderer.sparse_bytes(cap)
-        msg = [torch.zeros(msg_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
-        gathered_msg = [torch.zeros((world, msg_bytes), dtype=torch.uint8, device=dev) for _ in range(2)] if root else None
-        stamps = [torch.zeros(ren.sparse_stamp_bytes(), dtype=torch.uint8, device=dev) for _ in range(2)] if root else None
-        asm_tag = [0, 0]  # per output buffer: 0 = first reassembly (paints everything), then 1, 2, ...
-        del probe
+    # ---- the timed path: the parity format, dense rows ----
+    main = FramePath(env, args.format, "dense" if args.format == "rgba32f" else args.gather, cams)
+    dt, kernel_ms = main.run_timed(args.steps, args.warmup)
+    rays_timed = rays_in(args.steps, args.warmup)
+    check_main = main.frame_check()
+    gather_main = main.gather_report() if dist_on else None
 
-    def assemble(b):
-        """root: turn what gather b delivered into the full frame b (same stream: no side stream, no events -- the host
-        cost of this Python loop matters at 60 us per frame)."""
-        if args.backend == "nccl":
-            works[b].wait()   # stream-side: the render stream waits for the collective, the host does not
-        recv = gathered_msg[b] if sparse else gathered[b]
-        if sparse:  # incremental: each output buffer keeps its frame, only tiles that lost their content are repainted
-            ren.assemble_sparse_incremental(recv.data_ptr(), cap, full[b].data_ptr(), stamps[b].data_ptr(), asm_tag[b], stream=stream.cuda_stream)
-            asm_tag[b] = 1 if asm_tag[b] >= 0xFFFFFFF0 else asm_tag[b] + 1
-        else:
-            ren.assemble(recv.data_ptr(), full[b].data_ptr(), stream=stream.cuda_stream)
+    # ---- N > 1: the display wire format (RGBA8, sparse tiles) timed the same way, reported next to the headline ----
+    alt = None
+    if dist_on and args.format == "rgba32f" and not args.no_alt:
+        ap = FramePath(env, "rgba8", args.gather, cams)
+        adt, akms = ap.run_timed(args.steps, args.warmup)
+        acheck = ap.frame_check()
+        if rank == 0:
+            alt = {"framebuffer_format": "rgba8", "what": "iround(c*255) RGBA8, the wire format of the reference's CUDA back end (src/update-cuda.cu:149-156); "
+                   "ranks send only their 16x16 tiles with content" if ap.sparse else "iround(c*255) RGBA8 rows",
+                   "value": rays_timed / adt / 1e6, "unit": "Mrays/s", "ms_per_step": adt / args.steps * 1e3, "kernel_ms": akms,
+                   "gather": ap.gather_report(), "gathered_frame_identical_to_single_gpu_frame": acheck}
+        ap.close()
 
-    def step():
-        """One frame per rank.  Pipelined over two buffer sets: the gather of frame k travels while frame k+1 renders,
-        and rank 0 reassembles frame k-1 behind its own render of frame k (everything on one stream per rank)."""
-        k = state["k"]
-        state["k"] = k + 1
-        if world == 1:
-            ren.update(cam, dev_fb=local[0].data_ptr(), stream=stream.cuda_stream, timed=False)
-            return
-        b = k & 1
-        if works[b] is not None:
-            works[b].wait()   # frame k-2 has left its send buffer (stream-side wait for NCCL, already complete for gloo)
-        if sparse:  # the kernel writes this rank's tiles with hits straight into the fixed-size message
-            ren.update_sparse(msg[b].data_ptr(), cap, cam, stream=stream.cuda_stream, timed=False)
-        else:
-            ren.update(cam, dev_fb=local[b].data_ptr(), stream=stream.cuda_stream, timed=False)
-        send = msg[b] if sparse else local[b]
-        recv = (gathered_msg[b] if sparse else gathered[b]) if root else None
-        if args.backend == "nccl":
-            # RCCL gather over xGMI, the only collective of the path; async: the next frame's render is enqueued behind
-            # this call without waiting for it.  (It starts after the work already on this stream, so rank 0's reassembly
-            # of frame k-2 out of the same receive buffer is finished by then.)
-            works[b] = dist.gather(send, list(recv.unbind(0)) if root else None, dst=0, async_op=True)
-        else:  # rehearsal only: host-staged gather through gloo
-            lc = send.cpu()
-            gl = [torch.empty_like(lc) for _ in range(world)] if root else None
-            works[b] = dist.gather(lc, gl, dst=0, async_op=True)
-            works[b].wait()
-            if root:
-                recv.copy_(torch.stack(gl))
-        if root and k >= 1:
-            assemble((k - 1) & 1)   # the previous frame: its gather had a whole render to arrive
+    # ---- N = 1, static camera: the same kernel over an orbit of 24 poses (frame time depends on the view) ----
+    orbit = None
+    if not dist_on and args.camera == "static" and args.workload == "config2" and not args.no_orbit:
+        ts = []
+        for i in range(n_orbit):
+            cam = orbit_pose(pkg, i, n_orbit)
+            for _ in range(2):
+                main.ren.update(cam, dev_fb=main.local[0].data_ptr(), stream=main.stream.cuda_stream, timed=False)
+            ts.append(float(np.median([main.ren.update(cam, dev_fb=main.local[0].data_ptr(), stream=main.stream.cuda_stream, timed=True) for _ in range(5)])))
+        ts = np.array(ts) * 1e3
+        orbit = {"poses": n_orbit, "what": "per-pose kernel time (median of 5 frames each, HIP events) on an orbit around the scene; `--camera orbit` times a moving camera instead",
+                 "median_us": float(np.median(ts)), "max_us": float(ts.max()), "min_us": float(ts.min())}
 
-    def flush():
-        """root: reassemble the last frame (inside the timed region: K steps deliver K full frames)."""
-        if world > 1 and root and state["k"] >= 1:
-            assemble((state["k"] - 1) & 1)
-
-    for _ in range(args.warmup):
-        step()
-    flush()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    flush()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    ev_ms = ev0.elapsed_time(ev1)
-
-    # per-launch duration of the dominant kernel from HIP events on its own stream (N=1: the timed region is K
-    # back-to-back launches of it; N>1: measured in a short extra pass, the timed region also holds the gather)
-    if world == 1:
-        kernel_ms = ev_ms / args.steps
-    else:
-        kernel_ms = float(np.mean([ren.update(cam, dev_fb=local[0].data_ptr(), stream=stream.cuda_stream, timed=True) for _ in range(10)]))
-
-    # outside the timed region: the reassembled N-rank frame must equal a single-context render of the same scene
-    frame_check = None
-    if world > 1 and rank == 0 and W * H <= 7680 * 4320:
-        ref = pkg.Renderer(scene, device=local_rank, flags=flags, fmt=fmt)
-        ref.update(cam)
-        last = (state["k"] - 1) & 1
-        frame_check = bool(np.array_equal(ref.download(), full[last].cpu().numpy()))
-        ref.cleanup_update()
-
-    result = None
     if rank == 0:
         arr = scene.arrays()
-        local_cnt = {k: cnt[k] for k in keys}
-        if args.kernel == "simple":  # the simple kernel evaluates every reference test, solving inline
-            local_cnt["tests_executed"], local_cnt["solves"] = local_cnt["tests"], local_cnt["tests"] // 16
-        flops_launch = algorithmic_flops(local_cnt, object_classes(arr))
+        cnt = dict(detail0)
+        table, table_src = load_flop_table()
+        if args.kernel == "simple":  # the simple kernel evaluates every reference test, solving inline: dense count
+            flops_launch = dense_reference_flops(cnt)
+        else:
+            flops_launch = algorithmic_flops(cnt, table)
+        dense_local = dense_reference_flops(cnt)
+        capped = flops_launch > dense_local
+        if capped:   # the executed-algorithm count may never exceed the dense as-written figure
+            flops_launch = dense_local
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
-        dense_flops = total["tests"] * 290.0  # the reference's as-written count: 286 expansion + ~4 solver per test
-        dense_equiv = dense_flops / (dt / args.steps) / 1e12
-        fb_bytes = float(ren.local_rows) * W * px_bytes
+        step_s = dt / args.steps
+        dense_frame = float(np.mean([290.0 * t for t in tot[:, 3]]))   # whole job, per frame
+        fb_bytes = float(main.ren.local_rows) * W * main.px_bytes
+        pmc = pmc_profile(args, world)
+        roof = {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                "traffic": (pmc or {}).get("traffic"), "traffic_unit": "bytes/launch",
+                "traffic_source": (f"{pmc['source']} (committed PMC passes of this command; not measured by this run)" if pmc and not pmc.get("stale") else
+                                   ("PMC summary is older than the kernel sources: dropped" if pmc else None)),
+                "kernel": "trace_tile_kernel" if args.kernel == "simple" else "wavefront_tile_kernel",
+                "kernel_ms": kernel_ms, "kernel_ms_source": "HIP events on the render stream inside the timed region",
+                "algorithmic_flops_per_launch": flops_launch, "algorithmic_flops_source": f"{table_src} (counting scalar over the kernel's own math) x device work counters by surface class",
+                "capped_at_dense_reference_count": capped, "dense_reference_flops_per_launch": dense_local,
+                "work_units_per_launch": {k: v for k, v in cnt.items()},
+                "reference_dense_flops_per_frame": dense_frame, "reference_equivalent_tflops": dense_frame / step_s / 1e12,
+                "time_vs_dense_algorithm_at_100pct_fp64_peak": (dense_frame / (FP64_VECTOR_PEAK_TFLOPS * 1e12 * world)) / step_s,
+                "hbm_write_gbs": fb_bytes / (kernel_ms * 1e-3) / 1e9, "hbm_frac": fb_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if pmc and "flops" in pmc:
+            roof["pmc_flops_per_launch"] = pmc["flops"]
+            roof["pmc_flops_formula"] = "(SQ_INSTS_VALU_ADD_F64 + SQ_INSTS_VALU_MUL_F64 + 2 x SQ_INSTS_VALU_FMA_F64) x 64 x active-lane fraction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 64)"
+            roof["pmc_active_lane_fraction"] = pmc["active_lane_fraction"]
+            roof["table_vs_pmc"] = flops_launch / pmc["flops"]
+            if not capped and not (0.9 <= roof["table_vs_pmc"] <= 1.1):
+                raise SystemExit(f"bench.py: flop table ({flops_launch:.4g}) and PMC-derived count ({pmc['flops']:.4g}) disagree by more than 10 %")
+        if pmc and "valu_busy" in pmc:
+            roof["valu_busy"], roof["valu_busy_formula"] = pmc["valu_busy"], pmc["valu_busy_formula"]
+        cam_txt = "camera identity" if args.camera == "static" else f"camera moving along an orbit of {n_orbit} poses (a new pose every frame)"
         result = {
             "metric": "Mrays/sec, 20spheres.yml @1920x1080 (weak-scaled with --gpus)" if args.workload == "config2" else f"Mrays/sec, {args.workload}",
-            "value": rays_per_frame * args.steps / dt / 1e6,
-            "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "frames_per_s": args.steps / dt,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{scene_name}.yml {W}x{H}, camera identity, {args.format.upper()} framebuffer", "objects": int(arr["coefs"].shape[0]),
-                       "lights": int(arr["light_p"].shape[0]), "rays_per_frame": rays_per_frame, "tests_per_frame": total["tests"],
-                       "kernel_mode": args.mode, "kernel": args.kernel, "framebuffer_format": args.format,
-                       "parallelism": f"rows band-cyclic x{world} (band {band}), gather to rank 0" if world > 1 else "single GPU"},
-            # bound: the FP64 vector (VALU) pipe -- no dense contraction exists in this path, so no MFMA; HBM traffic is
-            # the 16 B/pixel framebuffer write only.  `achieved` counts the operations the kernel's own algorithm executes.
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(args, world), "traffic_unit": "bytes/launch (PMC)",
-                         "kernel": "trace_tile_kernel" if args.kernel == "simple" else "wavefront_tile_kernel",
-                         "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_launch,
-                         "work_units_per_launch": {k: local_cnt[k] for k in keys},
-                         "reference_dense_flops_per_frame": dense_flops, "reference_equivalent_tflops": dense_equiv,
-                         "time_vs_dense_algorithm_at_100pct_fp64_peak": (dense_flops / (FP64_VECTOR_PEAK_TFLOPS * 1e12)) / (dt / args.steps),
-                         "hbm_write_gbs": fb_bytes / (kernel_ms * 1e-3) / 1e9, "hbm_frac": fb_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "value": rays_timed / dt / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "frames_per_s": args.steps / dt,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "rccl_ranks": dist.get_world_size() if (dist_on and args.backend == "nccl") else 0,
+            "config": {"workload": f"{scene_name}.yml {W}x{H}, {cam_txt}, {args.format.upper()} framebuffer", "objects": int(arr["coefs"].shape[0]),
+                       "lights": int(arr["light_p"].shape[0]), "rays_per_frame": int(rays_per_pose[0]) if len(cams) == 1 else float(np.mean(rays_per_pose)),
+                       "tests_per_frame": total0["tests"], "kernel_mode": args.mode, "kernel": args.kernel, "framebuffer_format": args.format,
+                       "parallelism": f"rows band-cyclic x{world} (band {args.band_rows}), {args.backend} gather to rank 0 + device reassembly" if dist_on else "single GPU"},
+            "roofline": roof,
         }
-        if frame_check is not None:
-            result["config"]["gathered_frame_identical_to_single_gpu_frame"] = frame_check
-        if world > 1 and sparse:
-            hdr = gathered_msg[(state["k"] - 1) & 1][:, :8].cpu().numpy().view(np.uint32)
-            result["config"]["gather"] = {"kind": "sparse tiles", "capacity_tiles_per_rank": cap, "bytes_per_rank": msg_bytes,
-                                          "dense_bytes_per_rank": int(mx * W * px_bytes), "tiles_sent_per_rank": [int(v) for v in hdr[:, 0]],
-                                          "overflow": bool(hdr[:, 1].any())}
-        elif world > 1:
-            result["config"]["gather"] = {"kind": "dense rows", "bytes_per_rank": int(mx * W * px_bytes)}
+        if orbit:
+            result["camera_orbit"] = orbit
+        if check_main is not None:
+            result["config"]["gathered_frame_identical_to_single_gpu_frame"] = check_main
+        if gather_main:
+            result["config"]["gather"] = gather_main
+        if alt:
+            result["config"]["alt"] = alt
         if not args.no_cpu_baseline and world == 1:
             O = graft.load_oracle()
             osc = O.load_scene(os.path.join(ROOT, "scenes", scene_name + ".yml")).with_size(W, H, max_refl)
+            cam0 = cams[0]
             t = time.perf_counter()
             for _ in range(args.cpu_frames):
-                _, ocnt = osc.render(cam, counters=False, nthreads=1), None
+                osc.render(cam0, counters=False, nthreads=1)
             cdt = time.perf_counter() - t
-            result["cpu_baseline"] = {"value": rays_per_frame * args.cpu_frames / cdt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            rpf = int(rays_per_pose[0])
+            result["cpu_baseline"] = {"value": rpf * args.cpu_frames / cdt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
                                       "frames_per_s": args.cpu_frames / cdt,
-                                      "sample": f"{args.cpu_frames} full frames of the same workload ({W}x{H}), 1 thread (the reference's CPU path is serial), "
-                                                f"oracle built gcc -O2 -ffp-contract=off; {cdt:.1f} s"}
+                                      "sample": f"{args.cpu_frames} full frames of the same workload ({W}x{H}), 1 thread (the reference's CPU path is serial, "
+                                                f"src/update-cpu.cpp:125-133), oracle built gcc -O2 -ffp-contract=off; {cdt:.1f} s"}
+            ncpu = os.cpu_count() or 1
+            nfr = max(2, min(4 * args.cpu_frames, ncpu))
+            t = time.perf_counter()
+            for _ in range(nfr):
+                osc.render(cam0, counters=False, nthreads=ncpu)
+            adt = time.perf_counter() - t
+            result["cpu_baseline_all_cores"] = {"value": rpf * nfr / adt / 1e6, "unit": "Mrays/s", "cores": ncpu, "kind": "port", "frames_per_s": nfr / adt,
+                                                "sample": f"{nfr} full frames, rows of the frame distributed over {ncpu} threads (os.cpu_count() of this box), same oracle build; {adt:.1f} s"}
             result["speedup_vs_cpu_1thread"] = result["value"] / result["cpu_baseline"]["value"]
+            result["speedup_vs_cpu_all_cores"] = result["value"] / result["cpu_baseline_all_cores"]["value"]
         print(json.dumps(result), flush=True)
-    ren.cleanup_update()
-    if world > 1:
+    main.close()
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="config2", help="config2 (default, weak-scaled with --gpus) | config1 | config3 | config4 | config5")
+    ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
+    ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "wavefront-nocull", "simple"],
+                    help="A/B switch; the product default is the culling wavefront kernel")
+    ap.add_argument("--camera", default="static", choices=["static", "orbit"],
+                    help="static = identity (BASELINE: fixed-camera synthetic frames); orbit = a new pose every frame (24 poses around the scene)")
+    ap.add_argument("--static-order", action="store_true", help="A/B: RT_FLAG_STATIC_ORDER (no launch-order feedback)")
+    ap.add_argument("--band-rows", type=int, default=16)
+    ap.add_argument("--format", default="auto", choices=["auto", "rgba32f", "rgba8"],
+                    help="framebuffer / wire format of the HEADLINE measurement.  rgba32f (default at every N) = the CPU back end's un-quantised floats, "
+                         "the parity format.  rgba8 = iround(c*255), what the reference's CUDA back end writes (src/update-cuda.cu:149-156); at N > 1 it "
+                         "is always timed as well and reported as config.alt")
+    ap.add_argument("--gather", default="sparse", choices=["sparse", "dense"],
+                    help="what a rank sends to rank 0 in the RGBA8 measurement (N > 1).  dense = its rows; sparse = only its 16x16 tiles that are not "
+                         "pure background, with their ids, in a fixed-size message (rt_render_sparse / rt_assemble_sparse)")
+    ap.add_argument("--sparse-capacity", type=int, default=0, help="tiles per rank a sparse message holds (0 = busiest rank of one untimed frame + 25 %% + 64)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (the product path). gloo stages the gather through host memory and lets several ranks share "
+                         "one GPU: only for rehearsing the N>1 code path on a 1-GPU box")
+    ap.add_argument("--force-dist", action="store_true", help="N = 1: run the N > 1 code path (process group, gather, reassembly) with one rank")
+    ap.add_argument("--no-alt", action="store_true")
+    ap.add_argument("--no-orbit", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args.gpus))
+        world = 1
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+    if world != args.gpus:   # never fall through to a run that measures something else than what was asked for
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    run_rank(args, world)
 
 
 if __name__ == "__main__":

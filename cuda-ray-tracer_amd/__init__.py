@@ -360,3 +360,21 @@ class Renderer:
         c = Counters()
         _check(lib().rt_get_counters(self._h, C.byref(c)))
         return c.as_dict()
+
+    def counters_detail(self):
+        """counters() plus the executed work split by surface class / culling kind / cubic solver branch (what bench.py's
+        flop accounting multiplies with the per-unit costs of profiles/flop_table.json)."""
+        d = self.counters()
+        raw = self.debug_counters()
+        if lib().rt_abi_version() >= 2:
+            d["executed_by_class"] = dict(unitsq=raw[32], quadric=raw[33], linear=raw[34], cubic=raw[35])
+            d["solves_by_class"] = dict(unitsq=raw[36], quadric=raw[37], linear=raw[38])
+            d["cull_by_kind"] = dict(tile=raw[39], primary=raw[40], shadow=raw[41])
+            d["cubic_branches"] = dict(cardano=raw[42], trig=raw[43], quad=raw[44], linear=raw[45])
+        else:   # ABI 1 library: one class per scene only (the counters are not split)
+            a = {"unitsq": 0, "quadric": 0, "linear": 0, "cubic": 0}
+            d["executed_by_class"] = dict(a, unitsq=d["tests_executed"])
+            d["solves_by_class"] = dict(unitsq=d["solves"], quadric=0, linear=0)
+            d["cull_by_kind"] = dict(tile=0, primary=0, shadow=d["cull_evals"])
+            d["cubic_branches"] = dict(cardano=0, trig=0, quad=0, linear=0)
+        return d

@@ -105,6 +105,7 @@ struct rt_ctx {
     double *d_camx = nullptr, *d_camy = nullptr; // per-column / per-row camera-plane coordinates
     size_t n_stamp_rows = 0;
     uint32_t frame = 0; // renders so far: selects the launch-order generation (FrameArgs::order_state)
+    uint32_t tag = 0;   // frame tag of the scan workgroups' tile words (FrameArgs::tile_state); unique per render, never 0
     uint32_t *h_listed = nullptr; // host-mapped words the kernel writes (FrameArgs::ord_host)
     bool ord_on = true;           // launch-order feedback in use (off while most tiles have hits)
 };
@@ -535,6 +536,11 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
                 (void) hipGetLastError();
             }
         }
+        if (rc == RT_OK && !(cfg.flags & RT_FLAG_SIMPLE) && fa.all_cullable && fa.n_tiles > 0) {
+            // one word per tile for the scan workgroups (rt_wavefront.hip, scan_tiles); all zero = "no frame has classified it"
+            hip_ok(hipMalloc((void **) &fa.tile_state, sizeof(uint32_t) * fa.n_tiles), "hipMalloc(tile state)") &&
+                hip_ok(hipMemset(fa.tile_state, 0, sizeof(uint32_t) * fa.n_tiles), "hipMemset(tile state)");
+        }
         if (rc != RT_OK) {
             std::string keep = g_last_error;
             rt_destroy(ctx);
@@ -544,7 +550,7 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
     }
     ctx->zero_counters = std::getenv("MI355RT_DEBUG_COUNTERS") != nullptr;
     if (ctx->zero_counters) { // room for the stamp rows of a diagnostic (STAMPS=1) build: one per wave
-        ctx->n_stamp_rows = (size_t) fa.n_tiles * 8; // one row per wave of the (up to) 2 * n_tiles workgroups of a launch
+        ctx->n_stamp_rows = (size_t) fa.n_tiles * 9 + 96; // one row per wave of the (up to) 2 * n_tiles + n_tiles / 16 + n_tiles / 64 + 2 workgroups of a launch
         if (hipMalloc((void **) &ctx->d_stamps, ctx->n_stamp_rows * 12 * sizeof(uint64_t) + 8) != hipSuccess) ctx->d_stamps = nullptr;
         else (void) hipMemset(ctx->d_stamps, 0, ctx->n_stamp_rows * 12 * sizeof(uint64_t));
     }
@@ -594,6 +600,15 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
         const unsigned long long ptr = (unsigned long long) (uintptr_t) ctx->d_stamps;
         RT_HIP(hipMemcpyAsync(ctx->d_counters + 31, &ptr, sizeof(ptr), hipMemcpyHostToDevice, stream));
         RT_HIP(hipStreamSynchronize(stream));
+    }
+    fa.n_scan = 0;
+    if (fa.tile_state && fa.tile_planes_ok && !(ctx->cfg.flags & RT_FLAG_NOSCAN)) {
+        if (ctx->tag >= 0x3FFFFFF0u) { // the tag is stored shifted by two bits: start over with clean words (once in 2^30 frames)
+            RT_HIP(hipMemsetAsync(fa.tile_state, 0, sizeof(uint32_t) * fa.n_tiles, stream));
+            ctx->tag = 0;
+        }
+        fa.frame_tag = ++ctx->tag;
+        fa.n_scan = (fa.n_tiles + RT_SCAN_TILES - 1) / RT_SCAN_TILES;
     }
     if (fa.order_state) { // rotate the launch-order generations: read k, write k+1, clear k+2
         fa.ord_read = ctx->frame % 3u;
@@ -795,6 +810,7 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     if (ctx->d_camx) (void) hipFree(ctx->d_camx);
     if (ctx->d_camy) (void) hipFree(ctx->d_camy);
     if (ctx->fa.order_state) (void) hipFree(ctx->fa.order_state);
+    if (ctx->fa.tile_state) (void) hipFree(ctx->fa.tile_state);
     if (ctx->h_listed) (void) hipHostFree(ctx->h_listed);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);

@@ -122,11 +122,19 @@ struct FrameArgs {
     uint32_t *order_state;
     uint32_t *ord_host;   // host-mapped {listed tiles, census} of the previous frame: sizes / switches later launches
     uint32_t ord_stride, ord_read, ord_write, ord_zero;
-    uint32_t ord_cap;     // list slots in this launch (the grid is ord_cap + n_tiles workgroups)
+    uint32_t ord_cap;     // list slots in this launch (the grid is n_scan + ord_cap + n_tiles workgroups)
     uint32_t ord_on;      // 0: index order this frame, census only
+    // Tile words (all_cullable scenes; rt_wavefront.hip, "tile words"): the first n_scan workgroups of the grid classify
+    // RT_SCAN_TILES tiles each and publish tile_state[t] = (frame_tag << 2) | EMPTY / NONEMPTY, paint workgroups paint the
+    // EMPTY ones, and the workgroup that gets tile t in index order leaves at once when the word says EMPTY.
+    uint32_t *tile_state; // [n_tiles], NULL = no scan workgroups
+    uint32_t frame_tag;   // unique per frame of this context, never 0, < 2^30
+    uint32_t n_scan;      // classifying workgroups in this launch
 };
 
 #define RT_TILE 16        // a workgroup renders a 16 x 16 pixel tile
+#define RT_SCAN_TILES 64  // tiles classified by one classifying workgroup: sixteen per wave
+#define RT_PAINT_TILES 16 // tiles one paint workgroup is responsible for: four per wave
 #define RT_ORD_HDR 16      // words before word[] in one generation of FrameArgs::order_state
 #define RT_ORD_MAX_TILES 262144u // 8K frames (129 600 tiles) included: the order still pays there (measured), the state is 20 B per tile and generation
 

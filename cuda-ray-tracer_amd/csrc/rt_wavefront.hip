@@ -44,6 +44,7 @@
 // an instantiation contains no code and no registers for a feature the scene does not have; the mirror-free
 // sphere/plane one fits 94 VGPRs (5 waves per SIMD).  DESIGN.md section 5 has the measurements behind each choice.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "rt_math.hpp"
 #include "rt_scene_dev.h"
@@ -95,7 +96,8 @@ __device__ __forceinline__ uint32_t tile_py(uint32_t tid) { return (tid >> 7) * 
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR>
 constexpr int wf_occupancy()
 {
-    int occ = HAS_CUBIC ? 2 : (HAS_MIRROR ? (HAS_GQ ? 3 : 4) : (HAS_GQ ? 4 : 5)); // 94 / 127 / 128 / 168 / ~200 VGPRs (strict, no counters)
+    int occ = HAS_CUBIC ? 2 : (HAS_MIRROR ? (HAS_GQ ? 3 : 4) : (HAS_GQ ? 3 : 5)); // 95 / 128 / 168 / ~200 VGPRs (strict, no counters); the
+                                                                                  // mirror-free general-quadric one needs 129-130 at 4
     if (!HAS_CUBIC && (COUNT || RT_FAST)) occ -= 1; // counters / the FMA build's different schedule need a few registers more
     if (!HAS_CUBIC && COUNT && RT_FAST && HAS_MIRROR) occ -= 1;
     occ += RT_WF_OCC_DELTA;
@@ -384,6 +386,135 @@ __device__ __forceinline__ unsigned long long primary_cone_mask(const UsEntry *u
         rel = sphere_in_cone(e.kx, e.ky, e.kz, e.r, e.inv_r, org, axis, cos_t);
     }
     return __ballot(rel);
+}
+
+// ---- tile words: who deals with an empty tile (all-sphere scenes) -------------------------------------------------------
+// 83 % of config 2's tiles are empty, and a workgroup per empty tile that loads its arguments, reads the launch-order state,
+// lets one wave test the tile, passes a barrier and paints 256 pixels holds a slot for ~2 us: 13 us of a 57 us frame at
+// 1080p, 280 of 640 us at 8K (measured piece by piece: `make DEBUG_EXITS=1`, tools/empty_exits.py).  So the work is split:
+//
+//   classify   the first workgroups of the grid test 64 tiles each against the spheres (a wave takes sixteen consecutive
+//              tiles, lane = (tile, sphere slot), four spheres per pass; the same five-plane pyramid test as the tile-level
+//              early-out further down) and publish one word per tile:  (frame_tag << 2) | EMPTY / NONEMPTY;
+//   paint      behind the list slots, one workgroup per 16 tiles paints the background of the EMPTY ones (up to 1 KB
+//              contiguous per store instruction), overlapping the tiles that trace;
+//   index slot the workgroup that gets tile t in index order reads word t in its first instructions -- the pointer and the
+//              tag are preloaded kernel arguments -- and leaves if it says EMPTY: one load, no argument fetch, no barrier.
+//
+// The four waves of an index-slot workgroup decide independently, so they must all see the SAME verdict: a word is decided
+// exactly once per frame, by compare-and-swap from a value with an older tag, and every reader acts only on a value that
+// carries this frame's tag.  A reader that does not find one polls (the classifying workgroups are the first of the grid, so
+// in practice the word is there); after RT_TILE_MAX_POLLS polls it decides the word itself -- TIMEOUT: "this tile is its own
+// workgroup's business", the pre-classification path with a barrier -- again by compare-and-swap, so if the classifier
+// wins the race the reader follows the classifier, and vice versa.  Nothing ever waits without a bound, and whatever the
+// dispatch order, every tile is either painted by a paint workgroup (EMPTY) or rendered / painted by exactly one tracing
+// workgroup (NONEMPTY, TIMEOUT): the words change the time, never the image.  Words are written with agent-scope atomics
+// and read with agent-scope loads (the workgroups involved may sit on different XCDs, whose L2s are not coherent for plain
+// accesses).
+constexpr uint32_t ST_EMPTY = 1u, ST_NONEMPTY = 2u, ST_TIMEOUT = 3u;
+#ifndef RT_TILE_MAX_POLLS
+#define RT_TILE_MAX_POLLS 48
+#endif
+
+__device__ __forceinline__ uint32_t tile_word_load(uint32_t *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// value of *w once it carries `tag`, deciding it as TIMEOUT if it does not come; per-lane (callers mask the lanes)
+__device__ __forceinline__ uint32_t tile_word_wait(uint32_t *w, uint32_t tag, uint32_t v)
+{
+    for (int it = 0; (v >> 2) != tag; ++it) {
+        if (it >= RT_TILE_MAX_POLLS) {
+            uint32_t expect = v;
+            if (__hip_atomic_compare_exchange_strong(w, &expect, (tag << 2) | ST_TIMEOUT, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                v = (tag << 2) | ST_TIMEOUT;
+            else
+                v = expect; // somebody decided it meanwhile (only values with this frame's tag are written during this launch)
+        } else {
+            __builtin_amdgcn_s_sleep(16);
+            v = tile_word_load(w);
+        }
+    }
+    return v;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void classify_tiles(const FrameArgs &fa, const UsEntry *us, uint32_t n_us, uint32_t *tile_state, uint32_t tag, uint32_t n_tiles,
+                                               uint32_t wave, uint32_t lane, Cnt<COUNT> &cnt)
+{
+    const uint32_t i = lane & 15u, sl = lane >> 4;
+    const uint32_t t = blockIdx.x * RT_SCAN_TILES + wave * 16u + i;
+    const bool tv = t < n_tiles;
+    uint32_t old = 0;
+    if (sl == 0 && tv) old = tile_word_load(tile_state + t); // some older frame's word: the compare value of the publication below
+    double kx = 0.0, ky = 0.0, kz = 0.0, r = 0.0, inv = 0.0;
+    if (sl < n_us) { // this lane's first sphere: requested before the kernel arguments are even there
+        const UsEntry *e = us + sl;
+        kx = e->kx; ky = e->ky; kz = e->kz; r = e->r; inv = e->inv_r;
+    }
+    const uint32_t tc = tv ? t : n_tiles - 1u;
+    const uint32_t tile_x = tc % fa.tiles_x, tile_y = tc / fa.tiles_x;
+    const uint32_t x0 = tile_x * RT_TILE, y0l = tile_y * RT_TILE;
+    const uint32_t x1 = x0 + RT_TILE - 1 < fa.width ? x0 + RT_TILE - 1 : fa.width - 1;
+    const uint32_t y1l = y0l + RT_TILE - 1 < fa.local_rows ? y0l + RT_TILE - 1 : fa.local_rows - 1;
+    const double gy0 = (double) global_row(fa, y0l), gy1 = (double) global_row(fa, y1l);
+    const TilePlanes P = tile_planes(fa, fa.cx_a * ((double) x0 - 0.5) + fa.cx_b, fa.cx_a * ((double) x1 + 0.5) + fa.cx_b,
+                                     fa.cy_a * (gy0 - 0.5) + fa.cy_b, fa.cy_a * (gy1 + 0.5) + fa.cy_b);
+    const D3 org{fa.origin[0], fa.origin[1], fa.origin[2]};
+    bool rel = sl < n_us && sphere_in_pyramid(kx, ky, kz, r, inv, org, P);
+    for (uint32_t base = 4; base < n_us; base += 4) { // wave-uniform trip count
+        const uint32_t j = base + sl;
+        if (j < n_us) {
+            const UsEntry *e = us + j;
+            rel = rel || sphere_in_pyramid(e->kx, e->ky, e->kz, e->r, e->inv_r, org, P);
+        }
+    }
+    if (!fa.tile_planes_ok) rel = true; // (the launcher starts no classifying workgroups then)
+    unsigned long long m = __ballot(rel);
+    m |= m >> 32;
+    m |= m >> 16; // bit i: some sphere reaches into tile i of this wave
+    const bool nonempty = (m >> i) & 1ull;
+    if (sl == 0 && tv && (old >> 2) != tag) {
+        uint32_t expect = old;
+        __hip_atomic_compare_exchange_strong(tile_state + t, &expect, (tag << 2) | (nonempty ? ST_NONEMPTY : ST_EMPTY), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT); // fails only if a reader gave up on us (TIMEOUT): its decision stands
+    }
+    if (lane == 0) {
+        const uint32_t first = blockIdx.x * RT_SCAN_TILES + wave * 16u;
+        const uint32_t nt = first >= n_tiles ? 0u : (n_tiles - first < 16u ? n_tiles - first : 16u);
+        cnt.add(7, (unsigned long long) nt * n_us);
+    }
+}
+
+// one workgroup per RT_PAINT_TILES tiles: background of the tiles classified EMPTY (src/update-cpu.cpp:93-95)
+__device__ __forceinline__ void paint_tiles(const FrameArgs &fa, uint32_t *tile_state, uint32_t tag, uint32_t n_tiles, void *fb, const F3 &bg, uint32_t block,
+                                            uint32_t wave, uint32_t lane)
+{
+    const uint32_t sub = lane >> 4, j0 = lane & 15u;
+    const uint32_t t = block * RT_PAINT_TILES + wave * 4u + sub;
+    const bool tv = t < n_tiles;
+    uint32_t v = (tag << 2) | ST_NONEMPTY; // lanes without a word of their own
+    if (j0 == 0 && tv) v = tile_word_wait(tile_state + t, tag, tile_word_load(tile_state + t));
+    const unsigned long long em = __ballot(j0 == 0 && tv && (v & 3u) == ST_EMPTY);
+    if (!((em >> (16u * sub)) & 1ull)) return; // this lane's tile is traced (or handled) by a workgroup of its own
+    const uint32_t tile_x = t % fa.tiles_x, tile_y = t / fa.tiles_x;
+    const uint32_t x = tile_x * RT_TILE + j0, y0l = tile_y * RT_TILE;
+    if (x >= fa.width) return;
+    if (fa.rgba8) {
+        uchar4 px;
+        px.x = (unsigned char) (int) (bg.x * 255.0f + 0.5f);
+        px.y = (unsigned char) (int) (bg.y * 255.0f + 0.5f);
+        px.z = (unsigned char) (int) (bg.z * 255.0f + 0.5f);
+        px.w = 255;
+        uchar4 *dst = reinterpret_cast<uchar4 *>(fb) + (size_t) y0l * fa.width + x;
+#pragma unroll
+        for (uint32_t row = 0; row < RT_TILE; row++)
+            if (y0l + row < fa.local_rows) dst[(size_t) row * fa.width] = px;
+    } else {
+        const float4 px = make_float4(bg.x, bg.y, bg.z, 1.0f);
+        float4 *dst = reinterpret_cast<float4 *>(fb) + (size_t) y0l * fa.width + x;
+#pragma unroll
+        for (uint32_t row = 0; row < RT_TILE; row++)
+            if (y0l + row < fa.local_rows) dst[(size_t) row * fa.width] = px;
+    }
 }
 
 // Phase A.  PRIMARY: every lane's ray starts at the frame's origin, so the unit spheres are first culled against
@@ -696,7 +827,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     const unsigned char *hot_us,      // gscene + fa.off_us: the unit-sphere table
     const uint32_t *hot_ord_rd,       // the launch-order generation this frame reads (fa.order_state + ord_read * ord_stride)
     uint32_t hot_n_us, uint32_t hot_ord_cap, uint32_t hot_n_tiles,
-    uint32_t hot_flags,               // 1: fa.all_cullable   2: launch-order lists in use (fa.order_state && fa.ord_on)
+    uint32_t hot_flags,               // 1: fa.all_cullable   2: launch-order lists in use (fa.order_state && fa.ord_on)   4: paint workgroups
+    uint32_t *hot_tile_state,         // fa.tile_state (NULL: no tile words in this launch: every tile's own workgroup decides)
+    uint32_t hot_frame_tag, uint32_t hot_n_scan, // fa.frame_tag, fa.n_scan (classifying workgroups)
     const FrameArgs fa, const unsigned char *__restrict__ gscene,
                                                               const DevLight *__restrict__ glight, void *__restrict__ fb,
                                                               unsigned long long *__restrict__ counters,
@@ -745,6 +878,49 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     Cnt<COUNT> cnt;
     const F3 bg{fa.bg[0], fa.bg[1], fa.bg[2]};
 
+    // ---- roles: [classify][list slots][paint][index slots]; `slot` counts the tracing workgroups (list slots, then index order) ----
+    constexpr bool ALL_SPHERES_POSSIBLE = !HAS_GQ && !HAS_CUBIC; // fa.all_cullable needs a scene of spheres only
+    const uint32_t ord_slots = (hot_flags & 2u) ? hot_ord_cap : 0u;
+    uint32_t slot = blockIdx.x;
+    uint32_t tstate = ST_TIMEOUT; // verdict on this workgroup's tile; TIMEOUT = decide here (no tile words, list slots, gave up polling)
+    if (ALL_SPHERES_POSSIBLE && hot_tile_state) { // launch-uniform
+        if (blockIdx.x < hot_n_scan) { // workgroup-uniform
+            classify_tiles<COUNT>(fa, reinterpret_cast<const UsEntry *>(hot_us), hot_n_us, hot_tile_state, hot_frame_tag, hot_n_tiles, wave, lane, cnt);
+            RT_STAMP(11);
+            RT_STAMP_FLUSH(counters, lane);
+            cnt.flush(counters);
+            return;
+        }
+        slot -= hot_n_scan;
+        if (slot >= ord_slots) {
+            // behind the list slots: one paint workgroup in front of every RT_PAINT_TILES index slots (its own sixteen tiles' slots),
+            // so that the painting -- HBM-bound -- runs beside the index slots, which are bound by the dispatch rate
+            const uint32_t q = slot - ord_slots;
+            if (hot_flags & 4u) {
+                const uint32_t grp = q / (RT_PAINT_TILES + 1u), pos = q - grp * (RT_PAINT_TILES + 1u);
+                if (pos == 0u) { // workgroup-uniform
+                    paint_tiles(fa, hot_tile_state, hot_frame_tag, hot_n_tiles, fb, bg, grp, wave, lane);
+                    RT_STAMP(11);
+                    RT_STAMP_FLUSH(counters, lane);
+                    return;
+                }
+                slot = ord_slots + grp * RT_PAINT_TILES + (pos - 1u);
+                if (slot - ord_slots >= hot_n_tiles) return; // the last group may be partial
+            }
+            // index slot of tile slot - ord_slots: its word decides, and every wave of the workgroup reads the same decided value
+            uint32_t *w = hot_tile_state + (slot - ord_slots);
+            uint32_t v = 0;
+            if (lane == 0) v = tile_word_wait(w, hot_frame_tag, tile_word_load(w));
+            tstate = (uint32_t) __builtin_amdgcn_readfirstlane((int) v) & 3u;
+            // EMPTY: a paint workgroup paints it and nothing else is to do.  (Counting builds count its rays further down;
+            // slot 0 may have frame duties when the launch-order lists are off.)
+            if (!COUNT && tstate == ST_EMPTY && slot != 0u) return;
+        }
+    }
+#ifdef RT_WF_DEBUG_EXITS
+    if ((hot_flags & 0x100u) && slot >= ord_slots) return; // timing experiment: index slots leave at once
+#endif
+
     // ---- launch order from the previous frame ----
     // The frame time is set by when the LAST expensive tile starts (a tile full of hits costs ~20x an empty one and
     // they cluster), so the tiles that had hits in the previous frame are started first, the ones with the most hits
@@ -761,18 +937,18 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     // tile-level early-out (below): lane j of wave 0 tests sphere j, whatever the tile -- so the entry is requested
     // before the tile is even known and its latency overlaps with the order-state reads
     double pkx = 0.0, pky = 0.0, pkz = 0.0, pr = 0.0, pinv = 0.0;
-    if ((hot_flags & 1u) && wave == 0 && lane < hot_n_us) {
+    if (ALL_SPHERES_POSSIBLE && (hot_flags & 1u) && wave == 0 && lane < hot_n_us) {
         const UsEntry *pe = reinterpret_cast<const UsEntry *>(hot_us) + lane;
         pkx = pe->kx; pky = pe->ky; pkz = pe->kz; pr = pe->r; pinv = pe->inv_r;
     }
     uint32_t *ord_wr = nullptr;
-    uint32_t tile = blockIdx.x;
+    uint32_t tile = slot;
     bool listed = false;  // this tile had hits in the previous frame
     bool listing = false; // this frame appends to the lists
     bool covered = false; // index-order slot whose tile a list slot renders: leaves before its first side effect
     if (fa.order_state && !fa.ord_on) { // launch-uniform: census only
         ord_wr = fa.order_state + (size_t) fa.ord_write * fa.ord_stride;
-        if (blockIdx.x == 0 && tid == 0) {
+        if (slot == 0 && tid == 0) {
             const uint32_t *ord_rd = fa.order_state + (size_t) fa.ord_read * fa.ord_stride;
             uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride;
             *reinterpret_cast<uint4 *>(z) = make_uint4(0, 0, 0, 0);
@@ -789,7 +965,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         const uint32_t cn_x = ord_rd[0], cn_y = ord_rd[1], cn_z = ord_rd[2], cn_w = ord_rd[3]; // listed tiles of class 4, 3, 2, 1
         const uint32_t census = ord_rd[4];                          // tiles with hits in the previous frame, 1 in 16 counted
         // the per-tile word of an index-order slot is requested with them (for a list slot: tile 0's, unused)
-        const uint32_t idx_tile = blockIdx.x >= hot_ord_cap ? blockIdx.x - hot_ord_cap : 0u;
+        const uint32_t idx_tile = slot >= hot_ord_cap ? slot - hot_ord_cap : 0u;
         const uint32_t w = ord_rd[RT_ORD_HDR + idx_tile]; // (position in its class list << 3) | class, 0 = had no hits
         // ask for the camera / frame part of the kernel arguments here, between issuing the order-state reads and using
         // them: otherwise the compiler sinks those loads below the order decode and a workgroup starts with three
@@ -800,15 +976,15 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         listing = census * 64u < hot_n_tiles;                        // the host's switch lags a few frames: same rule here
         const uint32_t e1 = cn_x, e2 = e1 + cn_y, e3 = e2 + cn_z, n_listed = e3 + cn_w;
         const uint32_t n_eff = n_listed < hot_ord_cap ? n_listed : hot_ord_cap;
-        if (blockIdx.x == 0 && tid == 0) {
+        if (slot == 0 && tid == 0) {
             uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride; // the generation the NEXT frame appends to
             *reinterpret_cast<uint4 *>(z) = make_uint4(0, 0, 0, 0);
             z[4] = 0;
             if (fa.ord_host) { fa.ord_host[0] = n_listed; fa.ord_host[1] = census; } // host-mapped: sizes / switches later launches
         }
-        if (blockIdx.x < hot_ord_cap) {
-            if (blockIdx.x >= n_eff) return; // workgroup-uniform
-            const uint32_t b = blockIdx.x;
+        if (slot < hot_ord_cap) {
+            if (slot >= n_eff) return; // workgroup-uniform
+            const uint32_t b = slot;
             const uint32_t k = b < e1 ? 0u : (b < e2 ? 1u : (b < e3 ? 2u : 3u));
             const uint32_t first = k == 0 ? 0u : (k == 1 ? e1 : (k == 2 ? e2 : e3));
             tile = ord_rd[RT_ORD_HDR + (1u + k) * hot_n_tiles + (b - first)];
@@ -827,6 +1003,12 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             }
         }
     }
+#ifdef RT_WF_DEBUG_EXITS
+    if ((hot_flags & 0x200u) && !listed) { // timing experiment: index slots leave after the order-state / tile-state loads have come back
+        asm volatile("" ::"s"(tile), "s"((uint32_t) covered), "s"(tstate));
+        return;
+    }
+#endif
     {
         // pixel of this lane: each wave covers an 8 x 8 quadrant of the tile (tile_px / tile_py)
         const uint32_t tile_x = tile % fa.tiles_x, tile_y = tile / fa.tiles_x;
@@ -841,7 +1023,18 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         // sphere_in_pyramid above: no division or square root on this path, which 83 % of config 2's workgroups take and
         // nothing else) against all spheres.  A tile that cannot be hit ends here: the other three waves never form a
         // ray, and the tile is just the background colour.
-        if (fa.all_cullable && fa.tile_planes_ok && !listed) { // launch-uniform x workgroup-uniform; a listed tile almost surely has hits again
+        if (ALL_SPHERES_POSSIBLE && tstate == ST_EMPTY) { // workgroup-uniform.  Only counting builds and slot 0 get here (see the role decode)
+            if (COUNT && !covered && inside) {
+                cnt.add(0);
+                cnt.add(3, fa.n_obj);
+            }
+            RT_STAMP_FLUSH(counters, lane);
+            cnt.flush(counters);
+            return;
+        }
+        // A tile whose word says NONEMPTY goes straight to phase A; TIMEOUT (no tile words in this launch, or nobody classified
+        // the tile in time) decides here.
+        if (ALL_SPHERES_POSSIBLE && fa.all_cullable && fa.tile_planes_ok && !listed && tstate == ST_TIMEOUT) { // launch-uniform x workgroup-uniform; a listed tile almost surely has hits again
             if (wave == 0) {
                 // this lane's sphere (first group of 64) was requested at the top of the kernel
                 const uint32_t x0 = tile_x * RT_TILE, y0l = tile_y * RT_TILE;
@@ -867,6 +1060,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             }
             if (covered) return; // workgroup-uniform
             lds_barrier();
+#ifdef RT_WF_DEBUG_EXITS
+            if ((hot_flags & 0x400u)) return; // timing experiment: leave after the barrier, no paint
+#endif
             if (s_live[0] == 0) { // workgroup-uniform: the tile is pure background (src/update-cpu.cpp:93-95)
                 if (inside && fa.sparse) { // sparse output: background tiles are not stored at all
                     cnt.add(0);
@@ -1161,18 +1357,18 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         if (HAS_MIRROR) asm volatile("" : "+v"(tid_));
         const uint32_t sx_ = (tile % fa.tiles_x) * RT_TILE + tile_px(tid_), sy_ = (tile / fa.tiles_x) * RT_TILE + tile_py(tid_);
         if (fa.sparse) { // launch-uniform: fb is a message (rt_pack_sparse's layout); only tiles with round-0 hits are in it
-            const uint32_t slot = s_sparse[0]; // workgroup-uniform
+            const uint32_t mslot = s_sparse[0]; // workgroup-uniform
             uint32_t *msg = reinterpret_cast<uint32_t *>(fb);
-            if (slot < fa.sparse_cap) {
+            if (mslot < fa.sparse_cap) {
                 uchar4 px;
                 px.x = (unsigned char) (int) (res.x * 255.0f + 0.5f);
                 px.y = (unsigned char) (int) (res.y * 255.0f + 0.5f);
                 px.z = (unsigned char) (int) (res.z * 255.0f + 0.5f);
                 px.w = 255;
                 const uint32_t off_tiles = (4u + fa.sparse_cap + 3u) & ~3u;
-                reinterpret_cast<uchar4 *>(msg + off_tiles)[(size_t) slot * 256u + tile_py(tid_) * 16u + tile_px(tid_)] = px;
-                if (tid == 0) msg[4u + slot] = tile;
-            } else if (slot != 0xFFFFFFFFu && tid == 0) {
+                reinterpret_cast<uchar4 *>(msg + off_tiles)[(size_t) mslot * 256u + tile_py(tid_) * 16u + tile_px(tid_)] = px;
+                if (tid == 0) msg[4u + mslot] = tile;
+            } else if (mslot != 0xFFFFFFFFu && tid == 0) {
                 msg[1] = 1u; // more tiles with hits than the message holds
             }
         } else if (sx_ < fa.width && sy_ < fa.local_rows) {
@@ -1219,15 +1415,22 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
 {
     using namespace RT_SYM(rtw);
     if (fa->n_tiles == 0) return hipSuccess;
-    const dim3 grid((fa->order_state && fa->ord_on) ? fa->ord_cap + fa->n_tiles : fa->n_tiles), block(WG);
+    const uint32_t n_scan = fa->tile_state ? fa->n_scan : 0u; // classifying workgroups; with them: paint workgroups, unless the output is sparse
+    const uint32_t n_paint = (n_scan && !fa->sparse) ? (fa->n_tiles + RT_PAINT_TILES - 1u) / RT_PAINT_TILES : 0u;
+    // index region: groups of one paint workgroup + RT_PAINT_TILES index slots (the last group may be partial: surplus slots leave)
+    const uint32_t n_index = n_paint ? n_paint * (RT_PAINT_TILES + 1u) : fa->n_tiles;
+    const dim3 grid(n_scan + ((fa->order_state && fa->ord_on) ? fa->ord_cap : 0u) + n_index), block(WG);
     const size_t lds = LdsLayout(fa->stage_bytes, fa->n_lights, fa->has_mirror != 0).total;
     const unsigned char *gs = reinterpret_cast<const unsigned char *>(gobj);
     const int sel = (count ? 8 : 0) | (fa->has_mirror ? 4 : 0) | (fa->n_gq ? 2 : 0) | (fa->n_cub ? 1 : 0);
     const bool ordering = fa->order_state && fa->ord_on;
     const unsigned char *hot_us = gs + fa->off_us;
     const uint32_t *hot_ord_rd = ordering ? fa->order_state + (size_t) fa->ord_read * fa->ord_stride : nullptr;
-    const uint32_t hot_flags = (fa->all_cullable ? 1u : 0u) | (ordering ? 2u : 0u);
-#define RT_LAUNCH(C, M, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q, M>), grid, block, lds, stream, hot_us, hot_ord_rd, fa->n_us, fa->ord_cap, fa->n_tiles, hot_flags, *fa, gs, glight, fb, counters, camx, camy)
+    uint32_t hot_flags = (fa->all_cullable ? 1u : 0u) | (ordering ? 2u : 0u) | (n_paint ? 4u : 0u);
+#ifdef RT_WF_DEBUG_EXITS
+    if (const char *dbg = getenv("MI355RT_DEBUG_EXIT")) hot_flags |= (uint32_t) atoi(dbg) << 8;
+#endif
+#define RT_LAUNCH(C, M, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q, M>), grid, block, lds, stream, hot_us, hot_ord_rd, fa->n_us, fa->ord_cap, fa->n_tiles, hot_flags, n_scan ? fa->tile_state : nullptr, fa->frame_tag, n_scan, *fa, gs, glight, fb, counters, camx, camy)
     switch (sel) {
     case 0: RT_LAUNCH(false, false, false, false); break;
     case 1: RT_LAUNCH(false, false, false, true); break;

@@ -68,6 +68,9 @@ typedef struct rt_scene_desc {
 #define RT_FLAG_STATIC_ORDER 16u /* wavefront kernel: start the tiles in index order every frame instead of starting
                                  the tiles that had hits in the previous frame first; same results, for A/B runs */
 
+#define RT_FLAG_NOSCAN 32u    /* wavefront kernel: no scan workgroups (every tile's own workgroup decides whether the tile is
+                                 empty and paints it); same results, for A/B runs */
+
 /* rt_config.format -- framebuffer pixel format */
 #define RT_FMT_RGBA32F 0u     /* 4 x float per pixel, alpha 1.0: the un-quantised colours the CPU back end
                                  produces (src/update-cpu.cpp:128-131) plus an alpha lane for 16-byte stores */

@@ -25,7 +25,7 @@ extern "C" hipError_t rt_launch_trace_fast(const FrameArgs *, const DevObject *,
 extern "C" hipError_t rt_launch_wavefront_strict(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, const double *, const double *, hipStream_t);
 extern "C" hipError_t rt_launch_wavefront_fast(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, const double *, const double *, hipStream_t);
 
-extern "C" size_t rt_wavefront_lds_bytes_strict(uint32_t, uint32_t, int);
+extern "C" size_t rt_wavefront_lds_bytes_strict(uint32_t, uint32_t, int, uint32_t);
 extern "C" hipError_t rt_launch_assemble_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" hipError_t rt_launch_pack_sparse_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t rt_launch_assemble_sparse_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, void *, uint32_t, uint32_t, hipStream_t);
@@ -474,10 +474,10 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
         l.len_u = 1.001 * std::sqrt(l.u2);
     }
 
-    if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror) > 160u * 1024u) {
+    if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u) > 160u * 1024u) {
         delete ctx;
         return fail(RT_ERR_SCENE, "rt_create: scene needs %zu bytes of LDS per workgroup (limit 160 KiB)",
-                    rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror));
+                    rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u));
     }
     int rc = RT_OK;
     auto hip_ok = [&](hipError_t err, const char *what) {

@@ -472,6 +472,9 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
         l.u2 = (l.dxx + l.dyy) + l.dzz;
         l.inv_uu = l.u2 > 0.0 ? 1.0 / l.u2 : 0.0;
         l.len_u = 1.001 * std::sqrt(l.u2);
+        bool finite = std::isfinite(l.color[0]) && std::isfinite(l.color[1]) && std::isfinite(l.color[2]);
+        for (uint32_t k = 0; k < sd->n_objects * 3u && finite; k++) finite = std::isfinite(sd->albedo[k]);
+        l.backface_exact = (!l.spherical && finite) ? 1u : 0u;
     }
 
     if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u) > 160u * 1024u) {
@@ -603,7 +606,7 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
     }
     fa.n_scan = 0;
     if (fa.tile_state && fa.tile_planes_ok && !(ctx->cfg.flags & RT_FLAG_NOSCAN)) {
-        if (ctx->tag >= 0x3FFFFFF0u) { // the tag is stored shifted by two bits: start over with clean words (once in 2^30 frames)
+        if (ctx->tag >= 0x1FFFFFF0u) { // the tag is stored shifted by three bits: start over with clean words (once in 2^29 frames)
             RT_HIP(hipMemsetAsync(fa.tile_state, 0, sizeof(uint32_t) * fa.n_tiles, stream));
             ctx->tag = 0;
         }

@@ -76,6 +76,11 @@ struct alignas(16) DevLight {
     double dxx, dyy, dzz, dxy, dxz, dyz; // products of sdir components (COEF_2 of surface_impl.h:28)
     double u2;                           // (dxx + dyy) + dzz
     double inv_uu, len_u;                // 1 / |sdir|^2 and 1.001 |sdir|: culling only
+    // 1: a hit that faces away from this (directional) light may skip it altogether, shadow test and shading: its term is
+    // ((albedo / pi) * colour) * max(0, n.l) = finite * 0 = +0, and accumulating +0 changes nothing (include/light_impl.h:43,
+    // src/update-cpu.cpp:74).  Set by rt_create when this light's colour and every albedo of the scene are finite.
+    uint32_t backface_exact;
+    uint32_t pad_;
 };                                       // 144 B
 static_assert(sizeof(DevLight) == 144, "DevLight layout");
 
@@ -125,10 +130,10 @@ struct FrameArgs {
     uint32_t ord_cap;     // list slots in this launch (the grid is n_scan + ord_cap + n_tiles workgroups)
     uint32_t ord_on;      // 0: index order this frame, census only
     // Tile words (all_cullable scenes; rt_wavefront.hip, "tile words"): the first n_scan workgroups of the grid classify
-    // RT_SCAN_TILES tiles each and publish tile_state[t] = (frame_tag << 2) | EMPTY / NONEMPTY, paint workgroups paint the
+    // RT_SCAN_TILES tiles each and publish tile_state[t] = (frame_tag << 3) | EMPTY / NONEMPTY / COVERED, paint workgroups paint the
     // EMPTY ones, and the workgroup that gets tile t in index order leaves at once when the word says EMPTY.
     uint32_t *tile_state; // [n_tiles], NULL = no scan workgroups
-    uint32_t frame_tag;   // unique per frame of this context, never 0, < 2^30
+    uint32_t frame_tag;   // unique per frame of this context, never 0, < 2^29
     uint32_t n_scan;      // classifying workgroups in this launch
 };
 

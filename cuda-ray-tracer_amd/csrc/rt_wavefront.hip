@@ -414,7 +414,7 @@ __device__ __forceinline__ unsigned long long primary_cone_mask(const UsEntry *u
 //
 //   classify   the first workgroups of the grid test 64 tiles each against the spheres (a wave takes sixteen consecutive
 //              tiles, lane = (tile, sphere slot), four spheres per pass; the same five-plane pyramid test as the tile-level
-//              early-out further down) and publish one word per tile:  (frame_tag << 2) | EMPTY / NONEMPTY;
+//              early-out further down) and publish one word per tile:  (frame_tag << 3) | EMPTY / NONEMPTY / COVERED;
 //   paint      behind the list slots, one workgroup per 16 tiles paints the background of the EMPTY ones (up to 1 KB
 //              contiguous per store instruction), overlapping the tiles that trace;
 //   index slot the workgroup that gets tile t in index order reads word t in its first instructions -- the pointer and the
@@ -430,7 +430,8 @@ __device__ __forceinline__ unsigned long long primary_cone_mask(const UsEntry *u
 // workgroup (NONEMPTY, TIMEOUT): the words change the time, never the image.  Words are written with agent-scope atomics
 // and read with agent-scope loads (the workgroups involved may sit on different XCDs, whose L2s are not coherent for plain
 // accesses).
-constexpr uint32_t ST_EMPTY = 1u, ST_NONEMPTY = 2u, ST_TIMEOUT = 3u;
+constexpr uint32_t ST_EMPTY = 1u, ST_NONEMPTY = 2u, ST_TIMEOUT = 3u, ST_COVERED = 4u; // COVERED: not empty, and a list slot of this launch renders it
+constexpr uint32_t ST_BITS = 3u, ST_MASK = 7u;
 #ifndef RT_TILE_MAX_POLLS
 #define RT_TILE_MAX_POLLS 48
 #endif
@@ -440,11 +441,11 @@ __device__ __forceinline__ uint32_t tile_word_load(uint32_t *w) { return __hip_a
 // value of *w once it carries `tag`, deciding it as TIMEOUT if it does not come; per-lane (callers mask the lanes)
 __device__ __forceinline__ uint32_t tile_word_wait(uint32_t *w, uint32_t tag, uint32_t v)
 {
-    for (int it = 0; (v >> 2) != tag; ++it) {
+    for (int it = 0; (v >> ST_BITS) != tag; ++it) {
         if (it >= RT_TILE_MAX_POLLS) {
             uint32_t expect = v;
-            if (__hip_atomic_compare_exchange_strong(w, &expect, (tag << 2) | ST_TIMEOUT, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                v = (tag << 2) | ST_TIMEOUT;
+            if (__hip_atomic_compare_exchange_strong(w, &expect, (tag << ST_BITS) | ST_TIMEOUT, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                v = (tag << ST_BITS) | ST_TIMEOUT;
             else
                 v = expect; // somebody decided it meanwhile (only values with this frame's tag are written during this launch)
         } else {
@@ -457,7 +458,7 @@ __device__ __forceinline__ uint32_t tile_word_wait(uint32_t *w, uint32_t tag, ui
 
 template <bool COUNT>
 __device__ __forceinline__ void classify_tiles(const FrameArgs &fa, const UsEntry *us, uint32_t n_us, uint32_t *tile_state, uint32_t tag, uint32_t n_tiles,
-                                               uint32_t wave, uint32_t lane, Cnt<COUNT> &cnt)
+                                               const uint32_t *ord_rd, uint32_t ord_cap, uint32_t wave, uint32_t lane, Cnt<COUNT> &cnt)
 {
     const uint32_t i = lane & 15u, sl = lane >> 4;
     const uint32_t t = blockIdx.x * RT_SCAN_TILES + wave * 16u + i;
@@ -491,9 +492,24 @@ __device__ __forceinline__ void classify_tiles(const FrameArgs &fa, const UsEntr
     m |= m >> 32;
     m |= m >> 16; // bit i: some sphere reaches into tile i of this wave
     const bool nonempty = (m >> i) & 1ull;
-    if (sl == 0 && tv && (old >> 2) != tag) {
+    if (sl == 0 && tv && (old >> ST_BITS) != tag) {
+        uint32_t st = nonempty ? ST_NONEMPTY : ST_EMPTY;
+        if (nonempty && ord_rd) { // launch-order lists in use: does a list slot of this launch render the tile?  (the test of the index slots, made here
+                                  // once, so that the index slot of a covered tile leaves after one load as well)
+            const uint32_t cn0 = ord_rd[0], cn1 = ord_rd[1], cn2 = ord_rd[2], cn3 = ord_rd[3];
+            const uint32_t e1 = cn0, e2 = e1 + cn1, e3 = e2 + cn2, n_listed = e3 + cn3;
+            const uint32_t n_eff = n_listed < ord_cap ? n_listed : ord_cap;
+            const uint32_t w = ord_rd[RT_ORD_HDR + t]; // (position in its class list << 3) | class: a hint where to look, possibly stale
+            const uint32_t cls = w & 7u, pos = w >> 3;
+            if (cls >= 1u && cls <= 4u && pos < n_tiles) {
+                const uint32_t k = 4u - cls;
+                const uint32_t first = k == 0 ? 0u : (k == 1 ? e1 : (k == 2 ? e2 : e3));
+                const uint32_t count = k == 0 ? cn0 : (k == 1 ? cn1 : (k == 2 ? cn2 : cn3));
+                if (pos < count && first + pos < n_eff && ord_rd[RT_ORD_HDR + (1u + k) * n_tiles + pos] == t) st = ST_COVERED;
+            }
+        }
         uint32_t expect = old;
-        __hip_atomic_compare_exchange_strong(tile_state + t, &expect, (tag << 2) | (nonempty ? ST_NONEMPTY : ST_EMPTY), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+        __hip_atomic_compare_exchange_strong(tile_state + t, &expect, (tag << ST_BITS) | st, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT); // fails only if a reader gave up on us (TIMEOUT): its decision stands
     }
     if (lane == 0) {
@@ -510,9 +526,9 @@ __device__ __forceinline__ void paint_tiles(const FrameArgs &fa, uint32_t *tile_
     const uint32_t sub = lane >> 4, j0 = lane & 15u;
     const uint32_t t = block * RT_PAINT_TILES + wave * 4u + sub;
     const bool tv = t < n_tiles;
-    uint32_t v = (tag << 2) | ST_NONEMPTY; // lanes without a word of their own
+    uint32_t v = (tag << ST_BITS) | ST_NONEMPTY; // lanes without a word of their own
     if (j0 == 0 && tv) v = tile_word_wait(tile_state + t, tag, tile_word_load(tile_state + t));
-    const unsigned long long em = __ballot(j0 == 0 && tv && (v & 3u) == ST_EMPTY);
+    const unsigned long long em = __ballot(j0 == 0 && tv && (v & ST_MASK) == ST_EMPTY);
     if (!((em >> (16u * sub)) & 1ull)) return; // this lane's tile is traced (or handled) by a workgroup of its own
     const uint32_t tile_x = t % fa.tiles_x, tile_y = t / fa.tiles_x;
     const uint32_t x = tile_x * RT_TILE + j0, y0l = tile_y * RT_TILE;
@@ -944,7 +960,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     uint32_t tstate = ST_TIMEOUT; // verdict on this workgroup's tile; TIMEOUT = decide here (no tile words, list slots, gave up polling)
     if (ALL_SPHERES_POSSIBLE && hot_tile_state) { // launch-uniform
         if (blockIdx.x < hot_n_scan) { // workgroup-uniform
-            classify_tiles<COUNT>(fa, reinterpret_cast<const UsEntry *>(hot_us), hot_n_us, hot_tile_state, hot_frame_tag, hot_n_tiles, wave, lane, cnt);
+            classify_tiles<COUNT>(fa, reinterpret_cast<const UsEntry *>(hot_us), hot_n_us, hot_tile_state, hot_frame_tag, hot_n_tiles,
+                                  (hot_flags & 2u) ? hot_ord_rd : nullptr, hot_ord_cap, wave, lane, cnt);
             RT_STAMP(11);
             RT_STAMP_FLUSH(counters, lane);
             cnt.flush(counters);
@@ -970,10 +987,11 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             uint32_t *w = hot_tile_state + (slot - ord_slots);
             uint32_t v = 0;
             if (lane == 0) v = tile_word_wait(w, hot_frame_tag, tile_word_load(w));
-            tstate = (uint32_t) __builtin_amdgcn_readfirstlane((int) v) & 3u;
+            tstate = (uint32_t) __builtin_amdgcn_readfirstlane((int) v) & ST_MASK;
             // EMPTY: a paint workgroup paints it and nothing else is to do.  (Counting builds count its rays further down;
             // slot 0 may have frame duties when the launch-order lists are off.)
             if (!COUNT && tstate == ST_EMPTY && slot != 0u) return;
+            if (tstate == ST_COVERED) return; // a list slot renders (and counts) it; slot 0 is a list slot whenever the lists are in use
         }
     }
 #ifdef RT_WF_DEBUG_EXITS
@@ -1054,7 +1072,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             // A tile without hits writes nothing, so its word may be left over from an older frame of this generation:
             // the word is only a hint where to look, and the tile counts as covered iff that list entry really names it.
             const uint32_t cls = w & 7u, pos = w >> 3;
-            if (cls >= 1u && cls <= 4u && pos < hot_n_tiles) {
+            if (tstate == ST_TIMEOUT && cls >= 1u && cls <= 4u && pos < hot_n_tiles) { // (NONEMPTY: its classifier already found it uncovered)
                 const uint32_t k = 4u - cls;
                 const uint32_t first = k == 0 ? 0u : (k == 1 ? e1 : (k == 2 ? e2 : e3));
                 const uint32_t count = k == 0 ? cn_x : (k == 1 ? cn_y : (k == 2 ? cn_z : cn_w));
@@ -1292,13 +1310,15 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     if (valid) cnt.add(1);
                     // A directional light behind the surface contributes exactly +0 whether or not it is shadowed:
                     // surface_color multiplies by max(0.0f, (float) dot(n, light.p)) (include/light_impl.h:43), and the
-                    // colour it scales is finite.  Such lanes sit the shadow test out, and a light that is behind EVERY
+                    // colour it scales is finite (checked at rt_create).  Such lanes sit the shadow test out, and a light that is behind EVERY
                     // hit of the chunk costs nothing beyond this dot product.  (COUNT builds test them anyway: the
                     // reference-equivalent test count needs the index of the first blocker.)
                     bool wanted = valid;
-                    if (!COUNT && !lt.spherical) {
+                    if (!COUNT && lt.backface_exact) { // directional, all colours finite (rt_scene_dev.h)
                         const float lam = (float) dot3(nrm, D3{lt.p[0], lt.p[1], lt.p[2]});
                         wanted = valid && (0.0f < lam);
+                        // ... and the shading phase need not look at this light for these hits either: same bit as "blocked"
+                        if (valid && !wanted) atomicOr(&sshadow[h * L.shadow_words + (l >> 5)], 1u << (l & 31));
                         if (!__any(wanted)) continue;
                     }
                     double max_t;

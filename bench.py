@@ -115,31 +115,40 @@ def load_flop_table():
         return json.load(fh), os.path.relpath(path, ROOT)
 
 
-def dense_reference_flops(cnt):
-    """The reference's as-written FP64 count for the tests it would run: 286 per expansion + solver
-    (linear 1, quadratic miss 4 / hit 8, Cardano 26, trig 39), from the per-branch counters of the COUNT build."""
-    b = cnt.get("ref_branches")
-    if b:
-        return (286.0 * cnt["tests"] + 1.0 * b["linear"] + 4.0 * b["quad_miss"] + 8.0 * b["quad_hit"] + 26.0 * b["cardano"] + 39.0 * b["trig"]
-                + 79.0 * cnt["hits"])
-    return 290.0 * cnt["tests"] + 79.0 * cnt["hits"]
+def dense_reference_flops(cnt, table):
+    """The reference's as-written FP64 count for the frame: 286 per intersect_ray expansion + its solver branch
+    (linear 1, quadratic miss 4 / hit 8, Cardano 26, trig 39) + 79 per normal_vector.  Cubic tests by the branch the device
+    counted; a non-cubic test is a quadratic miss unless the kernel found a root worth solving (then: hit)."""
+    r = table["reference_dense"]
+    cb = cnt["cubic_branches"]
+    n_cubic = sum(cb.values())
+    solved = cnt["solves_by_class"]["unitsq"] + cnt["solves_by_class"]["quadric"]
+    other = max(0, cnt["tests"] - n_cubic)
+    f = r["expansion"] * cnt["tests"] + r["quadratic_miss"] * other + (r["quadratic_hit"] - r["quadratic_miss"]) * min(solved, other)
+    f += r["cardano"] * cb["cardano"] + r["trig"] * cb["trig"] + r["quadratic_hit"] * cb["quad"] + r["linear"] * cb["linear"]
+    return float(f + r["normal_vector"] * cnt["hits"])
 
 
-def algorithmic_flops(cnt, table):
-    """FP64 operations one frame of the wavefront kernel executes: executed units (device counters, per surface class)
-    x the counted cost of each unit."""
+def algorithmic_flops(cnt, table, arr):
+    """FP64 operations one frame of the wavefront kernel executes: executed units (device counters of what the product build
+    executes, per surface class / culling kind / solver branch) x the counted cost of each unit (profiles/flop_table.json)."""
     u = table["units"]
-    ex = cnt["executed_by_class"]
-    so = cnt["solves_by_class"]
-    cu = cnt["cull_by_kind"]
+    ex, so, cu, cb = cnt["executed_by_class"], cnt["solves_by_class"], cnt["cull_by_kind"], cnt["cubic_branches"]
+    cross = "_cross" if (ex["quadric"] or ex["cubic"]) else ""       # scenes with general quadrics / cubics form the mixed monomials too
+    kinds = arr["light_is_spherical"]
+    n_l = max(1, len(kinds))
+    f_pt = float(sum(1 for k in kinds if k)) / n_l                      # share of point lights (shadow rays are hits x lights)
     f = 0.0
     f += ex["unitsq"] * u["test_unitsq"] + ex["quadric"] * u["test_quadric"] + ex["linear"] * u["test_linear"] + ex["cubic"] * u["test_cubic_expand"]
-    f += so["unitsq"] * u["solve_quadratic"] + so["quadric"] * u["solve_quadratic"] + so["linear"] * u["solve_linear"]
-    cb = cnt["cubic_branches"]
-    f += cb["cardano"] * u["solve_cardano"] + cb["trig"] * u["solve_trig"] + cb["quad"] * u["solve_quadratic"] + cb["linear"] * u["solve_linear"]
-    f += cu["tile"] * u["cull_tile"] + cu["primary"] * u["cull_primary"] + cu["shadow"] * u["cull_shadow"]
-    f += cnt["primary_rays"] * u["primary_ray"] + cnt["shadow_rays"] * u["shadow_ray"] + cnt["reflect_rays"] * u["reflect_ray"]
-    f += cnt["hits"] * u["hit"]
+    f += so["unitsq"] * u["solve_unitsq"] + so["quadric"] * u["solve_quadric"] + so["linear"] * u["solve_linear"]
+    f += cb["cardano"] * u["cubic_cardano"] + cb["trig"] * u["cubic_trig"] + cb["quad"] * u["cubic_quadratic"] + cb["linear"] * u["cubic_linear"]
+    f += cu["tile"] * u["cull_tile"] + cu["primary"] * u["cull_primary"] + cu["shadow_directional"] * u["cull_shadow_directional"]
+    f += cu["shadow_point"] * u["cull_shadow_point"] + cu["records"] * u["cull_record"]
+    f += cnt["primary_rays"] * u["primary_ray" + cross] + cnt["reflect_rays"] * u["reflect_ray" + cross]
+    f += cnt["shadow_rays"] * ((1.0 - f_pt) * u["shadow_ray_considered_directional"] + f_pt * u["shadow_ray_considered_point"])
+    f += cnt["shadow_rays_traced"] * ((1.0 - f_pt) * u["shadow_ray_traced_directional" + cross] + f_pt * u["shadow_ray_traced_point" + cross])
+    f += cnt["hit_lights_shaded"] * ((1.0 - f_pt) * u["shade_directional"] + f_pt * u["shade_point"])
+    f += cnt["hits"] * u["hit" + cross] + (cnt["hits"] / 64.0) * u["chunk_ball"]
     return f
 
 
@@ -502,7 +511,9 @@ def run_rank(args, world):
         rc.update(cam)
         c = rc.counters()
         if detail0 is None:
-            detail0 = rc.counters_detail()
+            detail0 = rc.counters_detail() if args.kernel != "simple" else dict(c, executed_by_class=dict(unitsq=0, quadric=0, linear=0, cubic=0),
+                                                                                solves_by_class=dict(unitsq=c["solves"], quadric=0, linear=0),
+                                                                                cubic_branches=dict(cardano=0, trig=0, quad=0, linear=0))
         per_pose.append([c[k] for k in keys])
     rc.cleanup_update()
     tot = torch.tensor(per_pose, dtype=torch.int64, device=cdev)
@@ -553,16 +564,16 @@ def run_rank(args, world):
         cnt = dict(detail0)
         table, table_src = load_flop_table()
         if args.kernel == "simple":  # the simple kernel evaluates every reference test, solving inline: dense count
-            flops_launch = dense_reference_flops(cnt)
+            flops_launch = dense_reference_flops(cnt, table)
         else:
-            flops_launch = algorithmic_flops(cnt, table)
-        dense_local = dense_reference_flops(cnt)
+            flops_launch = algorithmic_flops(cnt, table, arr)
+        dense_local = dense_reference_flops(cnt, table)
         capped = flops_launch > dense_local
         if capped:   # the executed-algorithm count may never exceed the dense as-written figure
             flops_launch = dense_local
         achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
         step_s = dt / args.steps
-        dense_frame = float(np.mean([290.0 * t for t in tot[:, 3]]))   # whole job, per frame
+        dense_frame = float(np.mean([290.0 * t for t in tot[:, 3]]))   # whole job, per frame: 286 + a quadratic miss per reference test
         fb_bytes = float(main.ren.local_rows) * W * main.px_bytes
         pmc = pmc_profile(args, world)
         roof = {"bound": "valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,

@@ -17,6 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355rt.so")
 UPDATE_LIB_PATH = os.path.join(_HERE, "libmi355rt_update.so")
+MULTI_LIB_PATH = os.path.join(_HERE, "libmi355rt_multi.so")   # several GPUs behind one call; the only library that links RCCL
 
 RT_NCOEF = 20
 RT_FLAG_STRICT, RT_FLAG_FAST, RT_FLAG_COUNT, RT_FLAG_SIMPLE, RT_FLAG_NOCULL, RT_FLAG_STATIC_ORDER, RT_FLAG_NOSCAN = 0, 1, 2, 4, 8, 16, 32
@@ -25,13 +26,17 @@ RT_ERR_NO_DEVICE = -4
 
 # every symbol include/mi355rt.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = [
-    "rt_abi_version", "rt_last_error", "rt_scene_load_file", "rt_scene_new", "rt_scene_add_object",
+    "rt_abi_version", "rt_last_error", "rt_set_last_error", "rt_scene_load_file", "rt_scene_new", "rt_scene_add_object",
     "rt_scene_add_light", "rt_surface_make", "rt_scene_set_size", "rt_scene_set_max_reflections",
     "rt_scene_get_desc", "rt_scene_free", "rt_camera_matrix", "rt_create", "rt_render", "rt_local_rows", "rt_max_local_rows",
     "rt_row_map", "rt_pixel_bytes", "rt_device_fb", "rt_download", "rt_assemble", "rt_sparse_bytes", "rt_render_sparse", "rt_pack_sparse", "rt_assemble_sparse", "rt_sparse_stamp_bytes",
     "rt_assemble_sparse_incremental",
-    "rt_get_counters", "rt_debug_counters", "rt_destroy",
+    "rt_get_counters", "rt_get_counters_detail", "rt_debug_counters", "rt_destroy",
 ]
+# ... and the ones libmi355rt_multi.so exports
+MULTI_ABI_SYMBOLS = ["rt_create_multi", "rt_render_multi", "rt_multi_wait", "rt_multi_fb", "rt_multi_stream", "rt_multi_download", "rt_multi_info",
+                     "rt_multi_destroy"]
+RT_MULTI_SELF_EXCHANGE = 0x10000
 
 
 class RtError(RuntimeError):
@@ -57,6 +62,11 @@ class SceneDesc(C.Structure):
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("rank", C.c_uint32), ("world", C.c_uint32), ("band_rows", C.c_uint32),
                 ("flags", C.c_uint32), ("format", C.c_uint32)]
+
+
+class CountersDetail(C.Structure):
+    _fields_ = [("tests_executed", C.c_uint64 * 4), ("solves", C.c_uint64 * 3), ("cull_evals", C.c_uint64 * 5), ("cubic_branch", C.c_uint64 * 4),
+                ("shadow_rays_traced", C.c_uint64), ("hit_lights_shaded", C.c_uint64)]
 
 
 class Counters(C.Structure):
@@ -130,6 +140,7 @@ def lib():
         L.rt_sparse_stamp_bytes.restype = C.c_size_t
         L.rt_assemble_sparse_incremental.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp]
         L.rt_get_counters.argtypes = [vp, C.POINTER(Counters)]
+        L.rt_get_counters_detail.argtypes = [vp, C.POINTER(CountersDetail)]
         L.rt_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rt_destroy.argtypes = [vp]
         _lib = L
@@ -151,6 +162,31 @@ def _fptr(a):
 
 
 IDENTITY = np.eye(4, dtype=np.float64).reshape(16).copy()
+
+_mlib = None
+
+
+def multi_lib():
+    """libmi355rt_multi.so (rt_create_multi / rt_render_multi ...).  Loaded on demand: it links RCCL."""
+    global _mlib
+    if _mlib is None:
+        lib()   # the base library (and torch's HIP runtime, if torch is around) first
+        if not os.path.exists(MULTI_LIB_PATH):
+            raise RtError(-3, f"{MULTI_LIB_PATH} is missing: run __graft_entry__.build()")
+        M = C.CDLL(MULTI_LIB_PATH)
+        vp = C.c_void_p
+        M.rt_create_multi.argtypes = [C.POINTER(vp), C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        M.rt_render_multi.argtypes = [vp, C.POINTER(C.c_double), vp, C.POINTER(C.c_float)]
+        M.rt_multi_wait.argtypes = [vp]
+        M.rt_multi_fb.argtypes = [vp]
+        M.rt_multi_fb.restype = vp
+        M.rt_multi_stream.argtypes = [vp]
+        M.rt_multi_stream.restype = vp
+        M.rt_multi_download.argtypes = [vp, vp, C.c_size_t]
+        M.rt_multi_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        M.rt_multi_destroy.argtypes = [vp]
+        _mlib = M
+    return _mlib
 
 
 class Scene:
@@ -365,16 +401,56 @@ class Renderer:
         """counters() plus the executed work split by surface class / culling kind / cubic solver branch (what bench.py's
         flop accounting multiplies with the per-unit costs of profiles/flop_table.json)."""
         d = self.counters()
-        raw = self.debug_counters()
-        if lib().rt_abi_version() >= 2:
-            d["executed_by_class"] = dict(unitsq=raw[32], quadric=raw[33], linear=raw[34], cubic=raw[35])
-            d["solves_by_class"] = dict(unitsq=raw[36], quadric=raw[37], linear=raw[38])
-            d["cull_by_kind"] = dict(tile=raw[39], primary=raw[40], shadow=raw[41])
-            d["cubic_branches"] = dict(cardano=raw[42], trig=raw[43], quad=raw[44], linear=raw[45])
-        else:   # ABI 1 library: one class per scene only (the counters are not split)
-            a = {"unitsq": 0, "quadric": 0, "linear": 0, "cubic": 0}
-            d["executed_by_class"] = dict(a, unitsq=d["tests_executed"])
-            d["solves_by_class"] = dict(unitsq=d["solves"], quadric=0, linear=0)
-            d["cull_by_kind"] = dict(tile=0, primary=0, shadow=d["cull_evals"])
-            d["cubic_branches"] = dict(cardano=0, trig=0, quad=0, linear=0)
+        x = CountersDetail()
+        _check(lib().rt_get_counters_detail(self._h, C.byref(x)))
+        d["executed_by_class"] = dict(zip(("unitsq", "quadric", "linear", "cubic"), (int(v) for v in x.tests_executed)))
+        d["solves_by_class"] = dict(zip(("unitsq", "quadric", "linear"), (int(v) for v in x.solves)))
+        d["cull_by_kind"] = dict(zip(("tile", "primary", "shadow_directional", "shadow_point", "records"), (int(v) for v in x.cull_evals)))
+        d["shadow_rays_traced"], d["hit_lights_shaded"] = int(x.shadow_rays_traced), int(x.hit_lights_shaded)
+        d["cubic_branches"] = dict(zip(("cardano", "trig", "quad", "linear"), (int(v) for v in x.cubic_branch)))
         return d
+
+
+class MultiRenderer:
+    """init_update / update / cleanup_update over several GPUs of one node (rt_create_multi ...): the frame ends up on devices[0]."""
+
+    def __init__(self, scene, devices, band_rows=16, parts=1, flags=RT_FLAG_STRICT, fmt=RT_FMT_RGBA32F):
+        self._h = None
+        d = scene.desc() if isinstance(scene, Scene) else scene
+        self._desc = d
+        devs = (C.c_int * len(devices))(*[int(v) for v in devices])
+        h = C.c_void_p()
+        _check(multi_lib().rt_create_multi(C.byref(h), C.byref(d), devs, len(devices), int(band_rows), int(parts), int(flags), int(fmt)))
+        self._h = h
+        self.width, self.height, self.fmt = d.width, d.height, fmt
+        n, t = C.c_uint32(), C.c_uint32()
+        _check(multi_lib().rt_multi_info(self._h, C.byref(n), C.byref(t)))
+        self.n_contexts, self.transport = n.value, {0: "in place", 1: "device copies", 2: "rccl"}[t.value]
+
+    def update(self, cam=None, full_ptr=None, timed=True):
+        cam = np.ascontiguousarray(IDENTITY if cam is None else cam, dtype=np.float64).reshape(16)
+        ms = C.c_float(0.0)
+        _check(multi_lib().rt_render_multi(self._h, _dptr(cam), C.c_void_p(full_ptr) if full_ptr else None, C.byref(ms) if timed else None))
+        return ms.value if timed else None
+
+    def wait(self):
+        _check(multi_lib().rt_multi_wait(self._h))
+
+    def download(self):
+        dt = np.uint8 if self.fmt == RT_FMT_RGBA8 else np.float32
+        out = np.empty((self.height, self.width, 4), dtype=dt)
+        _check(multi_lib().rt_multi_download(self._h, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def cleanup_update(self):
+        if self._h:
+            multi_lib().rt_multi_destroy(self._h)
+            self._h = None
+
+    close = cleanup_update
+
+    def __del__(self):
+        try:
+            self.cleanup_update()
+        except Exception:
+            pass

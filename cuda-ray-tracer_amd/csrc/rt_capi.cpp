@@ -115,6 +115,8 @@ extern "C" int rt_abi_version(void) { return RT_ABI_VERSION; }
 
 extern "C" const char *rt_last_error(void) { return g_last_error.c_str(); }
 
+extern "C" void rt_set_last_error(const char *message) { g_last_error = message ? message : ""; }
+
 // ---- scene --------------------------------------------------------------------------------------------
 extern "C" int rt_scene_load_file(const char *path, rt_scene **out)
 {
@@ -491,8 +493,8 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
     hip_ok(hipMalloc((void **) &ctx->d_obj, blob.size()), "hipMalloc(scene)") &&
         hip_ok(hipMalloc((void **) &ctx->d_light, sizeof(DevLight) * (lights.size() ? lights.size() : 1)), "hipMalloc(lights)") &&
         hip_ok(hipMalloc(&ctx->d_fb, fb_bytes), "hipMalloc(framebuffer)") &&
-        hip_ok(hipMalloc((void **) &ctx->d_counters, sizeof(unsigned long long) * 32), "hipMalloc(counters)") &&
-        hip_ok(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * 32), "hipMemset(counters)") &&
+        hip_ok(hipMalloc((void **) &ctx->d_counters, sizeof(unsigned long long) * 64), "hipMalloc(counters)") &&
+        hip_ok(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * 64), "hipMemset(counters)") &&
         hip_ok(hipMemcpy(ctx->d_obj, blob.data(), blob.size(), hipMemcpyHostToDevice), "hipMemcpy(scene)") &&
         hip_ok(lights.empty() ? hipSuccess : hipMemcpy(ctx->d_light, lights.data(), sizeof(DevLight) * lights.size(), hipMemcpyHostToDevice), "hipMemcpy(lights)") &&
         hip_ok(hipEventCreate(&ctx->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&ctx->ev1), "hipEventCreate");
@@ -598,7 +600,10 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
     if (sparse) RT_HIP(hipMemsetAsync(fb, 0, 16, stream)); // message header: count, overflow
     const int count = (ctx->cfg.flags & RT_FLAG_COUNT) ? 1 : 0;
     const int rgba8 = ctx->cfg.format == RT_FMT_RGBA8;
-    if (count || ctx->zero_counters) RT_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * 28, stream));
+    if (count || ctx->zero_counters) {
+        RT_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * 28, stream)); // (word 31 holds the stamp rows' address)
+        RT_HIP(hipMemsetAsync(ctx->d_counters + 32, 0, sizeof(unsigned long long) * 32, stream));
+    }
     if (ctx->d_stamps) {
         const unsigned long long ptr = (unsigned long long) (uintptr_t) ctx->d_stamps;
         RT_HIP(hipMemcpyAsync(ctx->d_counters + 31, &ptr, sizeof(ptr), hipMemcpyHostToDevice, stream));
@@ -782,6 +787,24 @@ extern "C" int rt_get_counters(rt_ctx *ctx, rt_counters *out)
     out->solves = h[5];
     out->tests_executed = h[6];
     out->cull_evals = h[7];
+    return RT_OK;
+}
+
+extern "C" int rt_get_counters_detail(rt_ctx *ctx, rt_counters_detail *out)
+{
+    if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_get_counters_detail: null argument");
+    if (!ctx->counted) return fail(RT_ERR_INVALID, "rt_get_counters_detail: the last render was not done with RT_FLAG_COUNT");
+    if (ctx->cfg.flags & RT_FLAG_SIMPLE) return fail(RT_ERR_INVALID, "rt_get_counters_detail: the simple kernel does not split its counters");
+    unsigned long long h[18];
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(h, ctx->d_counters + 32, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; i++) out->tests_executed[i] = h[i];
+    for (int i = 0; i < 3; i++) out->solves[i] = h[4 + i];
+    for (int i = 0; i < 5; i++) out->cull_evals[i] = h[7 + i];
+    for (int i = 0; i < 4; i++) out->cubic_branch[i] = h[12 + i];
+    out->shadow_rays_traced = h[16];
+    out->hit_lights_shaded = h[17];
     return RT_OK;
 }
 

@@ -265,6 +265,25 @@ __device__ __noinline__ double intersect_cubic(const double *c, double ox, doubl
     return solve_quadlin(t2, t1, t0);
 }
 
+// The same value, inlined, also naming the solver branch that produced it (counting builds only):
+// 0 Cardano, 1 trigonometric, 2 quadratic, 3 linear / constant.
+__device__ __forceinline__ double intersect_cubic_branch(const double *c, double ox, double oy, double oz, double dx, double dy, double dz, int &branch)
+{
+    Mono m;
+    make_mono(m, D3{ox, oy, oz}, D3{dx, dy, dz});
+    double t3, t2, t1, t0;
+    cubic_poly(c, m, t3, t2, t1, t0);
+    if (fabs(t3) > EPS) {
+        const double a2 = t2 / t3, a1 = t1 / t3, a0 = t0 / t3; // the first lines of solve_cubic, to see which way it goes
+        const double q = (3.0 * a1 - a2 * a2) / 9.0;
+        const double r = (9.0 * a2 * a1 - 27.0 * a0 - 2.0 * a2 * a2 * a2) / 54.0;
+        branch = (q * q * q + r * r > 0) ? 0 : 1;
+        return solve_cubic(t3, t2, t1, t0);
+    }
+    branch = fabs(t2) > EPS ? 2 : 3;
+    return solve_quadlin(t2, t1, t0);
+}
+
 // intersect_ray, include/surface_impl.h:21-155: parameter of the root the reference would return.
 __device__ __forceinline__ double intersect(const double *__restrict__ c, uint32_t cls, const Mono &m)
 {

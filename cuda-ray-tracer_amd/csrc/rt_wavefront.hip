@@ -48,6 +48,7 @@
 
 #include "rt_math.hpp"
 #include "rt_scene_dev.h"
+#include "rt_wavefront_math.hpp"
 
 #ifndef RT_VARIANT
 #error "define RT_VARIANT=strict|fast"
@@ -99,6 +100,7 @@ constexpr int wf_occupancy()
     int occ = HAS_CUBIC ? 2 : (HAS_MIRROR ? (HAS_GQ ? 3 : 4) : (HAS_GQ ? 3 : 5)); // 95 / 128 / 168 / ~200 VGPRs (strict, no counters); the
                                                                                   // mirror-free general-quadric one needs 129-130 at 4
     if (!HAS_CUBIC && (COUNT || RT_FAST)) occ -= 1; // counters / the FMA build's different schedule need a few registers more
+    if (HAS_CUBIC && COUNT) occ = 1;                // counting builds inline the cubic path (they report its solver branch)
     if (!HAS_CUBIC && COUNT && RT_FAST && HAS_MIRROR) occ -= 1;
     occ += RT_WF_OCC_DELTA;
     return occ < 1 ? 1 : occ;
@@ -110,139 +112,50 @@ constexpr int wf_occupancy()
 
 // counters[]: 0 primary 1 shadow 2 reflect 3 tests (reference-equivalent: what the reference would have run) 4 hits
 //             5 solves executed 6 tests executed 7 cull evaluations
+//             32.. the work the PRODUCT build executes for the same frame, split up for the flop accounting of bench.py
+//             (rt_get_counters_detail).  A counting build runs every test the reference would run -- it needs the index of the
+//             first blocker -- but counts as "executed" only what the product build executes (lanes that face the light):
+//             32-35 tests executed per surface class (unit sphere, other quadric, plane, cubic)   36-38 root solves per class
+//             39-43 culling: tile pyramid, primary cone, shadow phase directional / point light, records formed
+//             44-47 cubic tests by solver branch   48 shadow rays traced (of counters[1] considered)   49 hits shaded per light
+enum { K_US = 0, K_GQ = 1, K_LIN = 2, K_CUB = 3 };
+enum { C_TILE = 0, C_PRIMARY = 1, C_SHADOW_DIR = 2, C_SHADOW_SPH = 3, C_RECORDS = 4 };
+constexpr int N_CNT_W = 18;
 template <bool COUNT>
 struct Cnt {
     __device__ __forceinline__ void add(int, unsigned long long = 1) {}
+    __device__ __forceinline__ void exec(int, unsigned long long) {}
+    __device__ __forceinline__ void solve(int) {}
+    __device__ __forceinline__ void cull(int, unsigned long long) {}
+    __device__ __forceinline__ void cubic(int, bool = true) {}
+    __device__ __forceinline__ void traced() {}
+    __device__ __forceinline__ void shaded() {}
     __device__ __forceinline__ void flush(unsigned long long *) {}
 };
 template <>
 struct Cnt<true> {
     unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t w[N_CNT_W] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // per thread and frame: 32 bits are plenty
     __device__ __forceinline__ void add(int i, unsigned long long n = 1) { v[i] += n; }
+    __device__ __forceinline__ void exec(int cls, unsigned long long n) { v[6] += n; w[cls] += (uint32_t) n; }
+    __device__ __forceinline__ void solve(int cls) { v[5] += 1; w[4 + cls] += 1; }
+    __device__ __forceinline__ void cull(int kind, unsigned long long n) { if (kind != C_RECORDS) v[7] += n; w[7 + kind] += (uint32_t) n; }
+    __device__ __forceinline__ void cubic(int branch, bool executed = true) // one test = expansion + solver
+    {
+        if (!executed) return;
+        v[5] += 1; v[6] += 1; w[K_CUB] += 1;
+        w[12] += branch == 0; w[13] += branch == 1; w[14] += branch == 2; w[15] += branch == 3; // (no indexed access: the counters stay in registers)
+    }
+    __device__ __forceinline__ void traced() { w[16] += 1; }
+    __device__ __forceinline__ void shaded() { w[17] += 1; }
     __device__ __forceinline__ void flush(unsigned long long *g)
     {
         for (int i = 0; i < 8; i++)
             if (v[i]) atomicAdd(&g[i], v[i]);
+        for (int i = 0; i < N_CNT_W; i++)
+            if (w[i]) atomicAdd(&g[32 + i], (unsigned long long) w[i]);
     }
 };
-
-// Does the reference's solver compute a root for these coefficients (include/surface_impl.h:138-154)?
-// false: it returns -1 without a division (negative discriminant, or a constant polynomial).
-__device__ __forceinline__ bool needs_solve(double t2, double t1, double t0)
-{
-    if (fabs(t2) > EPS) {
-        double delta = t1 * t1 - 4.0 * t2 * t0;
-        return !(delta < 0);
-    }
-    return fabs(t1) > EPS;
-}
-
-// Unit spheres (t2 = |d|^2 > 0): does the reference's solver produce a root that can pass a "t >= EPS" test?
-//   * discriminant < 0                      -> it returns -1                      (include/surface_impl.h:141-144)
-//   * t1 > 0 and t0 > 0 (origin outside, moving away) -> both roots are <= 0: with t2, t0 > 0 the computed
-//     discriminant is <= fl(t1*t1), a correctly rounded sqrt of that is <= t1, so (-t1 + sqrt)/(2 t2) <= 0 and
-//     (-t1 - sqrt)/(2 t2) < 0 in the reference's own floating-point evaluation, not just in exact arithmetic.
-// Either way neither the nearest-hit test (t >= EPS) nor the shadow test (t > EPS) can accept, so the sqrt and the
-// divisions need not be executed.  This removes the "own sphere" solve of every shadow ray that leaves a lit surface.
-__device__ __forceinline__ bool us_needs_solve(bool quad, double four_t2, double t1, double t0)
-{
-    if (quad) return !(t1 * t1 - four_t2 * t0 < 0) && !(t1 > 0.0 && t0 > 0.0);
-    return fabs(t1) > EPS;
-}
-
-// t1 / t0 per class table entry (rt_scene_dev.h).  Same sums as rtm::quadric_poly / include/surface_impl.h:54-103
-// with the exactly-zero groups left out (see RT_CLS_* in rt_scene_dev.h for why that is exact).  t1 and t0 are
-// separate functions because primary rays take t0 from a per-object table (it depends on the origin only).
-__device__ __forceinline__ double us_t1(const UsEntry &e, const Mono &m)
-{
-    return ((m.u1 + e.kx * m.d.x) + e.ky * m.d.y) + e.kz * m.d.z;
-}
-__device__ __forceinline__ double us_t0(const UsEntry &e, const Mono &m)
-{
-    return (((m.u0 + e.kx * m.o.x) + e.ky * m.o.y) + e.kz * m.o.z) + e.c;
-}
-__device__ __forceinline__ double lin_t1(const LinEntry &e, const Mono &m)
-{
-    return (e.kx * m.d.x + e.ky * m.d.y) + e.kz * m.d.z;
-}
-__device__ __forceinline__ double lin_t0(const LinEntry &e, const Mono &m)
-{
-    return ((e.kx * m.o.x + e.ky * m.o.y) + e.kz * m.o.z) + e.c;
-}
-__device__ __forceinline__ double gq_t2(const GqEntry &e, const Mono &m)
-{
-    return ((((e.x2 * m.dxx + e.y2 * m.dyy) + e.z2 * m.dzz) + e.xy * m.dxy) + e.xz * m.dxz) + e.yz * m.dyz;
-}
-__device__ __forceinline__ double gq_t1(const GqEntry &e, const Mono &m)
-{
-    return (((((((e.x2 * m.sx + e.y2 * m.sy) + e.z2 * m.sz) + e.xy * m.cxy) + e.xz * m.cxz) + e.yz * m.cyz) + e.kx * m.d.x) +
-            e.ky * m.d.y) + e.kz * m.d.z;
-}
-__device__ __forceinline__ double gq_t0(const GqEntry &e, const Mono &m)
-{
-    return ((((((((e.x2 * m.oxx + e.y2 * m.oyy) + e.z2 * m.ozz) + e.xy * m.oxy) + e.xz * m.oxz) + e.yz * m.oyz) + e.kx * m.o.x) +
-             e.ky * m.o.y) + e.kz * m.o.z) + e.c;
-}
-
-// Monomials of a ray in three parts, so that a part that is shared (origin of a whole chunk, direction of a
-// directional light) is formed once.  The cross / mixed ones are only formed when some table needs them.
-template <bool NEED_CROSS>
-__device__ __forceinline__ void mono_set_o(Mono &m, const D3 &o)
-{
-    constexpr bool need_cross = NEED_CROSS;
-    m.o = o;
-    m.oxx = o.x * o.x;
-    m.oyy = o.y * o.y;
-    m.ozz = o.z * o.z;
-    m.u0 = (m.oxx + m.oyy) + m.ozz;
-    m.oxy = m.oxz = m.oyz = 0.0;
-    if (need_cross) {
-        m.oxy = o.x * o.y;
-        m.oxz = o.x * o.z;
-        m.oyz = o.y * o.z;
-    }
-}
-template <bool NEED_CROSS>
-__device__ __forceinline__ void mono_set_d(Mono &m, const D3 &d)
-{
-    constexpr bool need_cross = NEED_CROSS;
-    m.d = d;
-    m.dxx = d.x * d.x;
-    m.dyy = d.y * d.y;
-    m.dzz = d.z * d.z;
-    m.u2 = (m.dxx + m.dyy) + m.dzz;
-    m.dxy = m.dxz = m.dyz = 0.0;
-    if (need_cross) {
-        m.dxy = d.x * d.y;
-        m.dxz = d.x * d.z;
-        m.dyz = d.y * d.z;
-    }
-}
-template <bool NEED_CROSS>
-__device__ __forceinline__ void mono_set_od(Mono &m)
-{
-    constexpr bool need_cross = NEED_CROSS;
-    m.sx = 2.0 * m.o.x * m.d.x;
-    m.sy = 2.0 * m.o.y * m.d.y;
-    m.sz = 2.0 * m.o.z * m.d.z;
-    m.u1 = (m.sx + m.sy) + m.sz;
-    m.cxy = m.cxz = m.cyz = 0.0;
-    if (need_cross) {
-        m.cxy = m.o.x * m.d.y + m.d.x * m.o.y;
-        m.cxz = m.o.x * m.d.z + m.d.x * m.o.z;
-        m.cyz = m.o.y * m.d.z + m.d.y * m.o.z;
-    }
-}
-
-// Nearest-hit rule of src/update-cpu.cpp:52-55 made order-independent: strict '<' with ascending object index
-// means the lowest index wins ties.
-__device__ __forceinline__ void accept(double t, int k, double &best_t, int &best)
-{
-    if (t >= EPS && t < MAX_T && (t < best_t || (t == best_t && k < best))) {
-        best_t = t;
-        best = k;
-    }
-}
 
 // The scene as staged in LDS.
 struct SceneLds {
@@ -312,88 +225,6 @@ __device__ __forceinline__ float wave_max_f(float v) RT_WAVE_REDUCE_F(fmaxf)
 __device__ __forceinline__ double wave_min(double v) RT_WAVE_REDUCE((t < v ? t : v))
 __device__ __forceinline__ double wave_max(double v) RT_WAVE_REDUCE((t > v ? t : v))
 #undef RT_WAVE_REDUCE
-
-// Conservative culling for primary rays: which unit spheres can ANY of this wave's 64 primary rays hit?
-// All rays leave the camera origin; they lie in the cone of half-angle theta around `axis` (the direction of
-// one central lane), theta = the largest angle between axis and a lane's direction.  A sphere (centre v
-// relative to the origin, radius r) can only be hit if it reaches into that cone; with h = v.axis and
-// rho = distance of the centre from the axis line, rho cos(theta) - h sin(theta) is the signed distance of the
-// centre from the cone's generator line (never larger than its distance to the cone), so the sphere is skipped
-// only when that exceeds r plus a margin (1e-6 relative + the cancellation error of the reference's own t0 for
-// huge coordinates).  Squared form, no sqrt / division.
-__device__ __forceinline__ bool sphere_in_cone(double kx, double ky, double kz, double r, double inv_r, const D3 &org, const D3 &axis,
-                                               double cos_t)
-{
-    bool rel;
-    {
-        // The squared comparison below (and the corner-pixel bound on the half-angle) needs a cone narrower than a
-        // half-space.  A 16-pixel block only gets that wide with absurd aspect ratios (a 106 x 2 image at 86 degrees:
-        // found by tests/tools/fuzz_parity.py), but then nothing is culled.
-        if (!(r < INFINITY) || !(cos_t > 0.2)) {
-            rel = true;
-        } else {
-            const double ccx = -0.5 * kx, ccy = -0.5 * ky, ccz = -0.5 * kz;
-            const double vx = ccx - org.x, vy = ccy - org.y, vz = ccz - org.z;
-            const double vv = vx * vx + vy * vy + vz * vz;
-            const double h = vx * axis.x + vy * axis.y + vz * axis.z;
-            double rho2 = vv - h * h;
-            rho2 = rho2 > 0.0 ? rho2 : 0.0;
-            const double v1 = fabs(vx) + fabs(vy) + fabs(vz);
-            const double s2 = ccx * ccx + ccy * ccy + ccz * ccz + org.x * org.x + org.y * org.y + org.z * org.z;
-            const double c = cos_t * (1.0 - 1e-9);               // a slightly wider cone
-            double sin2 = 1.0 - c * c;
-            sin2 = sin2 > 0.0 ? sin2 : 0.0;
-            const double sn = sqrt(sin2);
-            const double lim = r + 1e-6 * (v1 + r + 1.0) + 1e-12 * (s2 + 1.0) * inv_r;
-            const double rhs = lim + h * sn; // need rho * c <= rhs
-            rel = !(rhs < 0.0) && !(rho2 * c * c > rhs * rhs);
-        }
-    }
-    return rel;
-}
-
-// Tile-level early-out for all-sphere scenes.  The rays of a tile are t * M3 * (cx, cy, 1), t > 0, with cx / cy between
-// the camera-plane coordinates of the tile's first and last pixel (widened by half a pixel), i.e. they lie inside the
-// pyramid of five planes through the ray origin whose normals are M3^-T (1, 0, -cx0), (-1, 0, cx1), (0, 1, -cy0),
-// (0, -1, cy1), (0, 0, 1) (FrameArgs::tile_nt; no normalisation, no division, no square root).  A sphere whose centre lies
-// further than its radius plus the margin of sphere_in_cone outside ANY of the planes cannot be hit by a ray of the tile;
-// the comparison is made on squares.  Purely conservative: the verdict only decides whether phase A runs at all.
-struct TilePlanes {
-    D3 n[5];
-    double nn[5]; // n . n
-};
-
-__device__ __forceinline__ TilePlanes tile_planes(const FrameArgs &fa, double cx0, double cx1, double cy0, double cy1)
-{
-    const D3 c0{fa.tile_nt[0], fa.tile_nt[1], fa.tile_nt[2]}, c1{fa.tile_nt[3], fa.tile_nt[4], fa.tile_nt[5]}, c2{fa.tile_nt[6], fa.tile_nt[7], fa.tile_nt[8]};
-    TilePlanes P;
-    P.n[0] = D3{c0.x - cx0 * c2.x, c0.y - cx0 * c2.y, c0.z - cx0 * c2.z};
-    P.n[1] = D3{cx1 * c2.x - c0.x, cx1 * c2.y - c0.y, cx1 * c2.z - c0.z};
-    P.n[2] = D3{c1.x - cy0 * c2.x, c1.y - cy0 * c2.y, c1.z - cy0 * c2.z};
-    P.n[3] = D3{cy1 * c2.x - c1.x, cy1 * c2.y - c1.y, cy1 * c2.z - c1.z};
-    P.n[4] = c2;
-#pragma unroll
-    for (int k = 0; k < 5; k++) P.nn[k] = dot3(P.n[k], P.n[k]);
-    return P;
-}
-
-__device__ __forceinline__ bool sphere_in_pyramid(double kx, double ky, double kz, double r, double inv_r, const D3 &org, const TilePlanes &P)
-{
-    if (!(r < INFINITY)) return true;
-    const double ccx = -0.5 * kx, ccy = -0.5 * ky, ccz = -0.5 * kz;
-    const D3 v{ccx - org.x, ccy - org.y, ccz - org.z};
-    const double v1 = fabs(v.x) + fabs(v.y) + fabs(v.z);
-    const double s2 = ccx * ccx + ccy * ccy + ccz * ccz + org.x * org.x + org.y * org.y + org.z * org.z;
-    const double lim = r + 1e-6 * (v1 + r + 1.0) + 1e-12 * (s2 + 1.0) * inv_r; // as in sphere_in_cone
-    const double lim2 = lim * lim * (1.0 + 1e-9);
-    bool in = true;
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const double f = dot3(P.n[k], v);
-        in = in && !(f < 0.0 && f * f > lim2 * P.nn[k]); // beyond plane k by more than lim: outside
-    }
-    return in;
-}
 
 __device__ __forceinline__ unsigned long long primary_cone_mask(const UsEntry *us, uint32_t base, uint32_t end, const D3 &org,
                                                                 const D3 &axis, double cos_t, uint32_t lane)
@@ -515,7 +346,7 @@ __device__ __forceinline__ void classify_tiles(const FrameArgs &fa, const UsEntr
     if (lane == 0) {
         const uint32_t first = blockIdx.x * RT_SCAN_TILES + wave * 16u;
         const uint32_t nt = first >= n_tiles ? 0u : (n_tiles - first < 16u ? n_tiles - first : 16u);
-        cnt.add(7, (unsigned long long) nt * n_us);
+        cnt.cull(C_TILE, (unsigned long long) nt * n_us);
     }
 }
 
@@ -581,8 +412,8 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
         unsigned long long cand = 0;
         if (cone) {
             unsigned long long it = primary_cone_mask(S.us, base, end, m.o, axis, cos_t, lane);
-            if (lane == 0) cnt.add(7, end - base);
-            if (live) cnt.add(6, (unsigned long long) __popcll(it));
+            if (lane == 0) cnt.cull(C_PRIMARY, end - base);
+            if (live) cnt.exec(K_US, (unsigned long long) __popcll(it));
             while (it) { // wave-uniform loop over the spheres that reach into this wave's cone
                 const int b = __builtin_ctzll(it);
                 it &= it - 1;
@@ -593,7 +424,7 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
                 cand |= need ? (1ull << b) : 0ull;
             }
         } else {
-            if (live) cnt.add(6, end - base);
+            if (live) cnt.exec(K_US, end - base);
 #pragma unroll 4
             for (uint32_t j = base; j < end; j++) { // wave-uniform: LDS broadcast reads, no branches
                 const UsEntry e = S.us[j];
@@ -611,14 +442,14 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
             const double t1 = us_t1(e, m);
             const double t0 = us_t0(e, m);
             const double t = solve_quadlin(m.u2, t1, t0);
-            cnt.add(5);
+            cnt.solve(K_US);
             accept(t, (int) e.orig, best_t, best);
         }
     }
     for (uint32_t base = 0; HAS_GQ && base < fa.n_gq; base += 64) {
         const uint32_t end = (base + 64 < fa.n_gq) ? base + 64 : fa.n_gq;
         unsigned long long cand = 0;
-        if (live) cnt.add(6, end - base);
+        if (live) cnt.exec(K_GQ, end - base);
 #pragma unroll 2
         for (uint32_t j = base; j < end; j++) {
             const GqEntry e = S.gq[j];
@@ -632,7 +463,7 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
             const GqEntry e = S.gq[base + b];
             const double t0 = gq_t0(e, m);
             const double t = solve_quadlin(gq_t2(e, m), gq_t1(e, m), t0);
-            cnt.add(5);
+            cnt.solve(K_GQ);
             accept(t, (int) e.orig, best_t, best);
         }
     }
@@ -642,8 +473,8 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
         const double t0 = lin_t0(e, m);
         const double t = (fabs(t1) > EPS) ? -t0 / t1 : -1.0;
         if (live) {
-            cnt.add(5);
-            cnt.add(6);
+            cnt.solve(K_LIN);
+            cnt.exec(K_LIN, 1);
             accept(t, (int) e.orig, best_t, best);
         }
     }
@@ -651,117 +482,33 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
         for (uint32_t j = 0; j < fa.n_cub; j++) {
             const uint32_t k = __builtin_amdgcn_readfirstlane(S.cub[j]);
             if (live) {
-                const double t = intersect_cubic(gobj[k].c, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z);
-                cnt.add(5);
-                cnt.add(6);
+                double t;
+                if (COUNT) { // counting builds also report which solver branch ran (flop accounting of bench.py)
+                    int br;
+                    t = intersect_cubic_branch(gobj[k].c, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, br);
+                    cnt.cubic(br);
+                } else {
+                    t = intersect_cubic(gobj[k].c, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z);
+                }
                 accept(t, (int) k, best_t, best);
             }
         }
     }
 }
 
-// Conservative culling for phase B: can unit sphere (base + lane) block ANY shadow ray of this chunk towards
-// this light?  Returns the wave-uniform mask of table entries that must be tested.
-//
-// Every shadow ray of the chunk starts within `ball.R` of `ball.c` (hit point + 1e-2 * unit normal; R already
-// includes that bias) and runs along sdir (directional light: the same FP32-rounded direction for all) or to
-// within 1e-2 + 6e-8|e| of the light position (point light, parameter range (EPS, 1)).  A sphere can only block
-// if the reference's solver finds a root, i.e. if the ray's line (directional) / segment (point light) comes
-// within the sphere's radius of its centre.  By the triangle inequality that requires the centre to be within
-// r + R of the chunk's axis line / segment.  `lim` pads this with a margin that dwarfs every rounding
-// effect involved (1e-6 relative to the distances, plus the cancellation error of the reference's own t0 when
-// coordinates are huge); a larger margin only means a few more objects get tested.  Spheres without a real
-// radius carry r = +inf and are always tested; other classes are never culled.  No division, no sqrt.
-struct Ball {
-    double cx, cy, cz, R;
-};
-
 __device__ __forceinline__ unsigned long long relevant_mask(const UsEntry *us, uint32_t base, uint32_t end, const Ball &ball,
                                                             const DevLight &lt, uint32_t lane)
 {
-    bool rel = false;
     const uint32_t j = base + lane;
-    if (j < end) {
-        const UsEntry e = us[j];
-        const double r = e.r;
-        if (!(r < INFINITY)) {
-            rel = true; // +inf (not cullable) or NaN
-        } else {
-            const double ccx = -0.5 * e.kx, ccy = -0.5 * e.ky, ccz = -0.5 * e.kz; // centre (src/surface.cpp:10-12 inverted)
-            const double wx = ccx - ball.cx, wy = ccy - ball.cy, wz = ccz - ball.cz;
-            const double ww = wx * wx + wy * wy + wz * wz;
-            const double w1 = fabs(wx) + fabs(wy) + fabs(wz); // >= |w|
-            const double s2 = ccx * ccx + ccy * ccy + ccz * ccz + ball.cx * ball.cx + ball.cy * ball.cy + ball.cz * ball.cz;
-            if (!lt.spherical) {
-                const double along = wx * lt.sdir[0] + wy * lt.sdir[1] + wz * lt.sdir[2];
-                const double perp2 = ww - along * along * lt.inv_uu;
-                const double lim = r + ball.R + 1e-6 * (w1 + r + ball.R + 1.0) + 1e-12 * (s2 + 1.0) * e.inv_r;
-                // within reach of the axis, and not entirely behind the chunk (roots must be > EPS)
-                rel = !(perp2 > lim * lim) && !(along < -lim * lt.len_u);
-            } else {
-                const double ex = lt.p[0] - ball.cx, ey = lt.p[1] - ball.cy, ez = lt.p[2] - ball.cz;
-                const double ee = ex * ex + ey * ey + ez * ez;
-                const double e1 = fabs(ex) + fabs(ey) + fabs(ez);
-                const double we = wx * ex + wy * ey + wz * ez;
-                const double l2 = lt.p[0] * lt.p[0] + lt.p[1] * lt.p[1] + lt.p[2] * lt.p[2];
-                const double lim = r + ball.R + 1e-6 * (w1 + r + ball.R + e1 + 1.0) + 1e-12 * (s2 + l2 + 1.0) * e.inv_r;
-                const double lim2 = lim * lim;
-                // squared distance of the centre from the segment [ball.c, light]: closest point at parameter
-                // we/ee clamped to [0, 1]; the middle case is compared multiplied through by ee
-                if (!(we > 0.0)) rel = !(ww > lim2);
-                else if (!(we < ee)) rel = !((ww - 2.0 * we) + ee > lim2);
-                else rel = !(ww * ee - we * we > lim2 * ee);
-            }
-        }
-    }
-    return __ballot(rel);
-}
-
-// The light-independent half of relevant_mask for one (chunk, sphere): formed once per chunk in phase A' (lane = sphere) and
-// kept in LDS, so that a directional light's culling decision is eight operations per sphere instead of fifty.  Same
-// operations in the same order as relevant_mask, hence the same decisions.  Spheres that are never culled carry lim = +inf
-// (NaN radii give NaN: every comparison below is then false, i.e. "test it").
-struct alignas(16) CullRec {
-    double wx, wy, wz, ww, lim, pad;
-};                            // 48 B: three 16-byte LDS reads, conflict-free at this stride
-constexpr uint32_t CREC_MAX = 64; // records cover the first group of 64 spheres; further groups take relevant_mask
-
-__device__ __forceinline__ CullRec cull_record(const UsEntry &e, const Ball &ball)
-{
-    CullRec c;
-    const double r = e.r;
-    const double ccx = -0.5 * e.kx, ccy = -0.5 * e.ky, ccz = -0.5 * e.kz;
-    c.wx = ccx - ball.cx; c.wy = ccy - ball.cy; c.wz = ccz - ball.cz;
-    c.ww = c.wx * c.wx + c.wy * c.wy + c.wz * c.wz;
-    const double w1 = fabs(c.wx) + fabs(c.wy) + fabs(c.wz);
-    const double s2 = ccx * ccx + ccy * ccy + ccz * ccz + ball.cx * ball.cx + ball.cy * ball.cy + ball.cz * ball.cz;
-    c.lim = r + ball.R + 1e-6 * (w1 + r + ball.R + 1.0) + 1e-12 * (s2 + 1.0) * e.inv_r;
-    if (!(r < INFINITY)) c.lim = r; // +inf or NaN: always tested
-    c.pad = 0.0;
-    return c;
+    return __ballot(j < end && sphere_relevant(us[j], ball, lt));
 }
 
 __device__ __forceinline__ unsigned long long relevant_mask_directional(const CullRec *crec, uint32_t end, const DevLight &lt, uint32_t lane)
 {
-    bool rel = false;
-    if (lane < end) {
-        const CullRec c = crec[lane];
-        const double along = c.wx * lt.sdir[0] + c.wy * lt.sdir[1] + c.wz * lt.sdir[2];
-        const double perp2 = c.ww - along * along * lt.inv_uu;
-        rel = !(perp2 > c.lim * c.lim) && !(along < -c.lim * lt.len_u);
-    }
-    return __ballot(rel);
+    return __ballot(lane < end && crec_relevant(crec[lane], lt));
 }
 
-__device__ __forceinline__ void blend(F3 &res, float ratio, const F3 &c)
-{
-    // UPDATE_COLOR, src/update-cpu.cpp:100
-    res.x = (1.0f - ratio) * res.x + ratio * c.x;
-    res.y = (1.0f - ratio) * res.y + ratio * c.y;
-    res.z = (1.0f - ratio) * res.z + ratio * c.z;
-}
-
-__host__ __device__ inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+constexpr uint32_t CREC_MAX = 64; // culling records cover the first group of 64 spheres; further groups take relevant_mask
 
 // LDS carve-up (dynamic shared memory), shared by kernel and launcher.
 struct LdsLayout {
@@ -795,9 +542,12 @@ constexpr int NO_BLOCKER = 0x7fffffff;
 // object index.  `blocker` keeps the lowest blocking index seen; without COUNT any blocker ends the search.
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC>
 __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj,
-                                              const Mono &sm, double max_t, bool valid, const Ball *ballp, const CullRec *crec, const DevLight &lt,
+                                              const Mono &sm, double max_t, bool valid, bool prod, const Ball *ballp, const CullRec *crec, const DevLight &lt,
                                               uint32_t lane, Cnt<COUNT> &cnt)
 {
+    // valid: lanes whose ray is tested.  prod: lanes the product build tests (== valid there); a counting build tests more lanes --
+    // all that have a hit -- and counts executed work for the `prod` ones only (wave-level work: if any lane is one).
+    const bool prod_any = COUNT ? (bool) __any(prod) : true;
     int blocker = NO_BLOCKER;
     const bool quad = fabs(sm.u2) > EPS;
     const double four_t2 = 4.0 * sm.u2;
@@ -808,8 +558,8 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
             unsigned long long it = (base == 0 && !lt.spherical) ? relevant_mask_directional(crec, end, lt, lane) // wave-uniform choice
                                                                  : relevant_mask(S.us, base, end, *ballp, lt, lane); // (the ball is read from LDS here, not kept)
 
-            if (lane == 0) cnt.add(7, end - base);
-            if (valid) cnt.add(6, (unsigned long long) __popcll(it));
+            if (lane == 0 && prod_any) cnt.cull(lt.spherical ? C_SHADOW_SPH : C_SHADOW_DIR, end - base);
+            if (prod) cnt.exec(K_US, (unsigned long long) __popcll(it));
             while (it) { // wave-uniform loop over the spheres that survived the culling
                 const int b = __builtin_ctzll(it);
                 it &= it - 1;
@@ -819,7 +569,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
                 cand |= need ? (1ull << b) : 0ull;
             }
         } else {
-            if (valid) cnt.add(6, end - base);
+            if (prod) cnt.exec(K_US, end - base);
 #pragma unroll 4
             for (uint32_t j = base; j < end; j++) {
                 const UsEntry e = S.us[j];
@@ -835,7 +585,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
             const UsEntry e = S.us[base + b];
             if ((int) e.orig > blocker) continue;
             const double t = solve_quadlin(sm.u2, us_t1(e, sm), us_t0(e, sm));
-            cnt.add(5);
+            if (prod) cnt.solve(K_US);
             if (t > EPS && t < max_t) { // src/update-cpu.cpp:68
                 blocker = (int) e.orig;
                 if (!COUNT) break;
@@ -845,7 +595,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
     for (uint32_t base = 0; HAS_GQ && base < fa.n_gq; base += 64) {
         const uint32_t end = (base + 64 < fa.n_gq) ? base + 64 : fa.n_gq;
         unsigned long long cand = 0;
-        if (valid) cnt.add(6, end - base);
+        if (prod) cnt.exec(K_GQ, end - base);
 #pragma unroll 2
         for (uint32_t j = base; j < end; j++) {
             const GqEntry e = S.gq[j];
@@ -858,7 +608,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
             const GqEntry e = S.gq[base + b];
             if ((int) e.orig > blocker) continue;
             const double t = solve_quadlin(gq_t2(e, sm), gq_t1(e, sm), gq_t0(e, sm));
-            cnt.add(5);
+            if (prod) cnt.solve(K_GQ);
             if (t > EPS && t < max_t) {
                 blocker = (int) e.orig;
                 if (!COUNT) break;
@@ -870,8 +620,8 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
         const double t1 = lin_t1(e, sm), t0 = lin_t0(e, sm);
         const double t = (fabs(t1) > EPS) ? -t0 / t1 : -1.0;
         if (valid) {
-            cnt.add(5);
-            cnt.add(6);
+            if (prod) cnt.solve(K_LIN);
+            if (prod) cnt.exec(K_LIN, 1);
             if (t > EPS && t < max_t && (int) e.orig < blocker) blocker = (int) e.orig;
         }
     }
@@ -879,9 +629,14 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
         for (uint32_t j = 0; j < fa.n_cub; j++) {
             const uint32_t k = __builtin_amdgcn_readfirstlane(S.cub[j]);
             if (valid && (int) k < blocker && (COUNT || blocker == NO_BLOCKER)) {
-                const double t = intersect_cubic(gobj[k].c, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z);
-                cnt.add(5);
-                cnt.add(6);
+                double t;
+                if (COUNT) {
+                    int br;
+                    t = intersect_cubic_branch(gobj[k].c, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z, br);
+                    cnt.cubic(br, prod);
+                } else {
+                    t = intersect_cubic(gobj[k].c, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z);
+                }
                 if (t > EPS && t < max_t) blocker = (int) k;
             }
         }
@@ -1122,7 +877,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                                                  fa.cy_a * (gy0 - 0.5) + fa.cy_b, fa.cy_a * (gy1 + 0.5) + fa.cy_b);
                 const D3 org{fa.origin[0], fa.origin[1], fa.origin[2]};
                 unsigned long long any = __ballot(lane < fa.n_us && sphere_in_pyramid(pkx, pky, pkz, pr, pinv, org, P));
-                if (lane == 0) cnt.add(7, fa.n_us < 64 ? fa.n_us : 64);
+                if (lane == 0) cnt.cull(C_TILE, fa.n_us < 64 ? fa.n_us : 64);
                 for (uint32_t base = 64; base < fa.n_us; base += 64) {
                     const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
                     bool rel = false;
@@ -1131,7 +886,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                         rel = sphere_in_pyramid(e.kx, e.ky, e.kz, e.r, e.inv_r, org, P);
                     }
                     any |= __ballot(rel);
-                    if (lane == 0) cnt.add(7, end - base);
+                    if (lane == 0) cnt.cull(C_TILE, end - base);
                 }
                 if (lane == 0) s_live[0] = any != 0ull ? 1u : 0u;
             }
@@ -1287,6 +1042,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 if (lane == 0) sball[wave] = b;
                 // the light-independent half of the shadow-phase culling, lane = sphere (first group of 64)
                 if (lane < L.n_crec) screc[wave * L.n_crec + lane] = cull_record(S.us[lane], b);
+                if (lane == 0) cnt.cull(C_RECORDS, L.n_crec);
             }
             lds_barrier();
             RT_STAMP(5);
@@ -1313,20 +1069,20 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     // colour it scales is finite (checked at rt_create).  Such lanes sit the shadow test out, and a light that is behind EVERY
                     // hit of the chunk costs nothing beyond this dot product.  (COUNT builds test them anyway: the
                     // reference-equivalent test count needs the index of the first blocker.)
-                    bool wanted = valid;
-                    if (!COUNT && lt.backface_exact) { // directional, all colours finite (rt_scene_dev.h)
+                    bool wanted = valid; // the lanes the product build traces; a counting build traces every hit's ray (it needs the first blocker's index)
+                    if (lt.backface_exact) { // directional, all colours finite (rt_scene_dev.h)
                         const float lam = (float) dot3(nrm, D3{lt.p[0], lt.p[1], lt.p[2]});
                         wanted = valid && (0.0f < lam);
                         // ... and the shading phase need not look at this light for these hits either: same bit as "blocked"
-                        if (valid && !wanted) atomicOr(&sshadow[h * L.shadow_words + (l >> 5)], 1u << (l & 31));
-                        if (!__any(wanted)) continue;
+                        if (!COUNT && valid && !wanted) atomicOr(&sshadow[h * L.shadow_words + (l >> 5)], 1u << (l & 31));
+                        if (!COUNT && !__any(wanted)) continue;
                     }
                     double max_t;
                     if (lt.spherical) {
                         // shadow_ray, include/light_impl.h:19-21: (light - point) through FP32
                         max_t = 1.0;
                         const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]}; // re-read: not kept in registers across lights
-                        if (!COUNT) {
+                        {
                             // Same argument for a point light behind the surface: the shading term is
                             // max(0, (float) dot(n, normalize(l - p))) (include/light_impl.h:38-43), normalisation scales by
                             // a positive factor, so the sign is that of q = dot(n, l - p) unless q is lost in rounding --
@@ -1335,7 +1091,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                             const double q = dot3(nrm, D3{dx, dy, dz});
                             const double mag = fabs(nrm.x * dx) + fabs(nrm.y * dy) + fabs(nrm.z * dz);
                             wanted = valid && !(q < -1e-9 * mag);
-                            if (!__any(wanted)) continue;
+                            if (!COUNT && !__any(wanted)) continue;
                         }
                         const D3 sd{(double) (float) (lt.p[0] - p.x), (double) (float) (lt.p[1] - p.y), (double) (float) (lt.p[2] - p.z)};
                         mono_set_d<NEED_CROSS>(sm, sd);
@@ -1348,7 +1104,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                         sm.u2 = lt.u2;
                     }
                     mono_set_od<NEED_CROSS>(sm);
-                    const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC>(fa, S, gobj, sm, max_t, wanted, sball + c, screc + c * L.n_crec, lt, lane, cnt);
+                    if (wanted) cnt.traced();
+                    const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, screc + c * L.n_crec, lt,
+                                                                                 lane, cnt);
                     if (valid) {
                         // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
                         cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
@@ -1374,6 +1132,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     if (!blocked) {
                         const DevLight &lt = S.light[l];
                         F3 col = surface_color_pre(lt.p, lt.color, lt.spherical != 0, p, n, aop);
+                        cnt.shaded();
                         acc.x += col.x;
                         acc.y += col.y;
                         acc.z += col.z;

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -98,11 +98,26 @@ typedef struct rt_counters {
     uint64_t cull_evals;    /* bounding-sphere culling decisions evaluated (one lane each) */
 } rt_counters;
 
+/* The work the PRODUCT build executes for the frame of the last RT_FLAG_COUNT render, split the way the flop accounting needs
+ * it (bench.py multiplies each entry with the cost of that unit, counted by tools/count_flops.cpp over the kernel's own math).
+ * (A counting render itself traces more shadow rays than the product build -- it needs every first blocker's index for
+ * rt_counters.tests -- but counts as executed only what the product build executes.) */
+typedef struct rt_counters_detail {
+    uint64_t tests_executed[4]; /* per surface class: unit sphere, other quadric, plane, cubic */
+    uint64_t solves[3];         /* root solves per class: unit sphere, other quadric, plane (cubic: cubic_branch) */
+    uint64_t cull_evals[5];     /* culling decisions: tile pyramid, primary cone, shadow phase directional / point light; records formed */
+    uint64_t cubic_branch[4];   /* cubic tests by solver branch: Cardano, trigonometric, quadratic, linear / none (surface_impl.h:106-154) */
+    uint64_t shadow_rays_traced; /* of rt_counters.shadow_rays: those not skipped because the hit faces away from the light */
+    uint64_t hit_lights_shaded;  /* surface_color evaluations (light_impl.h:29) */
+} rt_counters_detail;
+
 typedef struct rt_ctx rt_ctx;
 typedef struct rt_scene rt_scene;
 
 int rt_abi_version(void);
 const char *rt_last_error(void);
+/* For layers built on this ABI (libmi355rt_multi.so): set the calling thread's error text. */
+void rt_set_last_error(const char *message);
 
 /* ---------------------------------------------------------------------------------------------------
  * Scene loading -- replaces Scene::load_from_file (include/scene.h:35, src/scene.cpp:154-203) and the
@@ -194,6 +209,7 @@ int rt_assemble_sparse_incremental(rt_ctx *ctx, const void *gathered_msgs, uint3
 
 /* Counters of the last render done with RT_FLAG_COUNT. */
 int rt_get_counters(rt_ctx *ctx, rt_counters *out);
+int rt_get_counters_detail(rt_ctx *ctx, rt_counters_detail *out); /* wavefront kernel only */
 
 /* Diagnostics: the raw device counter block (32 words).  Words 0-7 are rt_counters; words 8+ are per-phase
  * wave-cycle totals that only a library built with `make STAMPS=1` fills in. */
@@ -201,6 +217,35 @@ int rt_debug_counters(rt_ctx *ctx, uint64_t out[32]);
 
 /* Replaces cleanup_update (include/update.h:8). */
 int rt_destroy(rt_ctx *ctx);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Several GPUs of one node behind one call -- libmi355rt_multi.so (links librccl; libmi355rt.so itself does not).
+ * The reference is single-GPU (src/update-cuda.cu:160-190); BASELINE.json's north star tiles the rows over the GPUs of a
+ * node and gathers them on one.  One process: a context per (device, part) with the rows band-cyclic
+ * over all n_devices * parts contexts, every device rendering part after part on its own stream, finished parts
+ * travelling to devices[0] by ncclSend / ncclRecv over xGMI on a second stream while the next part renders, and
+ * rt_assemble restoring row order there.  host/src/update-hip.cpp uses it when MI355RT_DEVICES names more than one
+ * device, so update() (include/update.h:7) returns the whole frame whatever the number of GPUs.
+ *   devices    HIP ordinals; devices[0] is the root that ends up with the frame.  All distinct: RCCL.  One ordinal repeated
+ *              n times: the same choreography with device-to-device copies instead of RCCL (for a one-GPU box).
+ *   parts      contexts per device (0 = 1): more parts = finer overlap of transfer and rendering
+ *   flags      RT_FLAG_* of every context, plus RT_MULTI_SELF_EXCHANGE
+ * rt_render_multi: root_full_fb = device pointer on devices[0] receiving [height][width] pixels, or NULL for the object's
+ * own buffer (rt_multi_fb); enqueue-only unless ms is given (then: device time on the root from the start of its render
+ * to the end of the reassembly, transfers included).  rt_multi_stream() is the root stream the frame is complete on.
+ * ------------------------------------------------------------------------------------------------- */
+#define RT_MULTI_SELF_EXCHANGE 0x10000u /* one device: send its rows to itself through RCCL instead of rendering in place
+                                           (exercises the RCCL path on a one-GPU box) */
+typedef struct rt_multi rt_multi;
+int rt_create_multi(rt_multi **out, const rt_scene_desc *scene, const int *devices, uint32_t n_devices, uint32_t band_rows, uint32_t parts,
+                    uint32_t flags, uint32_t format);
+int rt_render_multi(rt_multi *m, const double cam[16], void *root_full_fb, float *ms);
+int rt_multi_wait(rt_multi *m);                       /* host waits until the last frame is complete on the root */
+void *rt_multi_fb(rt_multi *m);                       /* the object's own full-frame buffer on devices[0] */
+void *rt_multi_stream(rt_multi *m);                   /* hipStream_t on devices[0] */
+int rt_multi_download(rt_multi *m, void *host_dst, size_t bytes);
+int rt_multi_info(const rt_multi *m, uint32_t *n_contexts, uint32_t *transport /* 0 in place, 1 device copies, 2 RCCL */);
+int rt_multi_destroy(rt_multi *m);
 
 #ifdef __cplusplus
 }

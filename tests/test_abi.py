@@ -17,14 +17,30 @@ def declared_functions():
 
 
 def test_header_and_binding_agree(pkg):
-    assert declared_functions() == sorted(pkg.ABI_SYMBOLS)
+    assert declared_functions() == sorted(pkg.ABI_SYMBOLS + pkg.MULTI_ABI_SYMBOLS)
 
 
 def test_library_exports_every_declared_symbol(pkg):
+    """libmi355rt.so exports the single-GPU ABI, libmi355rt_multi.so (the only one that links RCCL) the rt_*_multi entry points."""
     lib = ctypes.CDLL(pkg.LIB_PATH)
+    multi = ctypes.CDLL(pkg.MULTI_LIB_PATH)
     for name in declared_functions():
-        assert hasattr(lib, name), name
-    assert lib.rt_abi_version() == 1
+        assert hasattr(multi if name in pkg.MULTI_ABI_SYMBOLS else lib, name), name
+    assert lib.rt_abi_version() == 2
+    needed = subprocess.run(["readelf", "-d", pkg.MULTI_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "librccl" in needed and "libmi355rt.so" in needed
+    base = subprocess.run(["readelf", "-d", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "librccl" not in base
+
+
+def test_multi_refuses_bad_device_lists(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    sc = pkg.Scene.load_from_file(scene_path("quadratic"))
+    with pytest.raises(pkg.RtError) as e:
+        pkg.MultiRenderer(sc, [0, 1])
+    assert e.value.code == pkg.RT_ERR_NO_DEVICE
 
 
 def test_update_backend_exports_reference_contract(pkg):

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "rt_scene_get_desc", "rt_scene_free", "rt_camera_matrix", "rt_create", "rt_render", "rt_local_rows", "rt_max_local_rows",
     "rt_row_map", "rt_pixel_bytes", "rt_device_fb", "rt_download", "rt_assemble", "rt_sparse_bytes", "rt_render_sparse", "rt_pack_sparse", "rt_assemble_sparse", "rt_sparse_stamp_bytes",
     "rt_assemble_sparse_incremental",
-    "rt_get_counters", "rt_get_counters_detail", "rt_debug_counters", "rt_destroy",
+    "rt_get_counters", "rt_get_counters_detail", "rt_debug_counters", "rt_debug_stamp_rows", "rt_destroy",
 ]
 # ... and the ones libmi355rt_multi.so exports
 MULTI_ABI_SYMBOLS = ["rt_create_multi", "rt_render_multi", "rt_multi_wait", "rt_multi_fb", "rt_multi_stream", "rt_multi_download", "rt_multi_info",
@@ -142,6 +142,7 @@ def lib():
         L.rt_get_counters.argtypes = [vp, C.POINTER(Counters)]
         L.rt_get_counters_detail.argtypes = [vp, C.POINTER(CountersDetail)]
         L.rt_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.rt_debug_stamp_rows.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.rt_destroy.argtypes = [vp]
         _lib = L
     return _lib
@@ -391,6 +392,15 @@ class Renderer:
         out = (C.c_uint64 * 32)()
         _check(lib().rt_debug_counters(self._h, out))
         return [int(v) for v in out]
+
+    def stamp_rows(self):
+        """Diagnostic builds: [n_rows, 16] uint64 per-wave rows of the last frame (see rt_debug_stamp_rows)."""
+        n = C.c_size_t()
+        _check(lib().rt_debug_stamp_rows(self._h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 16), dtype=np.uint64)
+        if n.value:
+            _check(lib().rt_debug_stamp_rows(self._h, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return out
 
     def counters(self):
         c = Counters()

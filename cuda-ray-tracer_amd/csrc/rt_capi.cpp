@@ -556,8 +556,8 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
     ctx->zero_counters = std::getenv("MI355RT_DEBUG_COUNTERS") != nullptr;
     if (ctx->zero_counters) { // room for the stamp rows of a diagnostic (STAMPS=1) build: one per wave
         ctx->n_stamp_rows = (size_t) fa.n_tiles * 9 + 96; // one row per wave of the (up to) 2 * n_tiles + n_tiles / 16 + n_tiles / 64 + 2 workgroups of a launch
-        if (hipMalloc((void **) &ctx->d_stamps, ctx->n_stamp_rows * 12 * sizeof(uint64_t) + 8) != hipSuccess) ctx->d_stamps = nullptr;
-        else (void) hipMemset(ctx->d_stamps, 0, ctx->n_stamp_rows * 12 * sizeof(uint64_t));
+        if (hipMalloc((void **) &ctx->d_stamps, ctx->n_stamp_rows * 16 * sizeof(uint64_t) + 8) != hipSuccess) ctx->d_stamps = nullptr;
+        else (void) hipMemset(ctx->d_stamps, 0, ctx->n_stamp_rows * 16 * sizeof(uint64_t));
     }
     *out = ctx;
     return RT_OK;
@@ -605,6 +605,7 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
         RT_HIP(hipMemsetAsync(ctx->d_counters + 32, 0, sizeof(unsigned long long) * 32, stream));
     }
     if (ctx->d_stamps) {
+        RT_HIP(hipMemsetAsync(ctx->d_stamps, 0, ctx->n_stamp_rows * 16 * sizeof(uint64_t), stream)); // rows of this frame only
         const unsigned long long ptr = (unsigned long long) (uintptr_t) ctx->d_stamps;
         RT_HIP(hipMemcpyAsync(ctx->d_counters + 31, &ptr, sizeof(ptr), hipMemcpyHostToDevice, stream));
         RT_HIP(hipStreamSynchronize(stream));
@@ -815,12 +816,24 @@ extern "C" int rt_debug_counters(rt_ctx *ctx, uint64_t out[32])
     RT_HIP(hipDeviceSynchronize());
     RT_HIP(hipMemcpy(out, ctx->d_counters, sizeof(uint64_t) * 32, hipMemcpyDeviceToHost));
     if (ctx->d_stamps) { // diagnostic build: sum the per-wave stamp rows into words 8..19
-        std::vector<uint64_t> rows(ctx->n_stamp_rows * 12);
+        std::vector<uint64_t> rows(ctx->n_stamp_rows * 16);
         RT_HIP(hipMemcpy(rows.data(), ctx->d_stamps, rows.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
         for (int i = 0; i < 12; i++) out[8 + i] = 0;
         for (size_t r = 0; r < ctx->n_stamp_rows; r++)
-            for (int i = 0; i < 12; i++) out[8 + i] += rows[r * 12 + i];
+            for (int i = 0; i < 12; i++) out[8 + i] += rows[r * 16 + i];
     }
+    return RT_OK;
+}
+
+extern "C" int rt_debug_stamp_rows(rt_ctx *ctx, uint64_t *out, size_t max_rows, size_t *n_rows)
+{
+    if (!ctx || !n_rows) return fail(RT_ERR_INVALID, "rt_debug_stamp_rows: null argument");
+    *n_rows = ctx->d_stamps ? ctx->n_stamp_rows : 0;
+    if (!out || !ctx->d_stamps) return RT_OK;
+    const size_t n = max_rows < ctx->n_stamp_rows ? max_rows : ctx->n_stamp_rows;
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(out, ctx->d_stamps, n * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -73,15 +73,18 @@ __device__ __forceinline__ uint32_t tile_py(uint32_t tid) { return (tid >> 7) * 
 // Diagnostic build only (make STAMPS=1): per-phase wave-cycle totals into counters[8..], read with
 // rt_debug_counters().  The product build contains no stamp.
 #ifdef RT_WF_STAMPS
-#define RT_STAMP_DECL unsigned long long ph_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long tl_ = clock64();
+#define RT_STAMP_DECL unsigned long long ph_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long tl_ = clock64(); const unsigned long long w0_ = wall_clock64(); unsigned long long info_ = 0;
 #define RT_STAMP(i) do { unsigned long long t_ = clock64(); ph_[i] += t_ - tl_; tl_ = t_; } while (0)
-// one private 12-word row per wave (pointer in counters[31]) -- no atomics, which would distort the timings
+// one private 16-word row per wave (pointer in counters[31]) -- no atomics, which would distort the timings.  Words 0-11: cycles
+// per phase; 12 / 13: constant-rate clock (100 MHz) at the wave's start / end, for tools/timeline.py
 #define RT_STAMP_FLUSH(c, lane) do { if ((lane) == 0) { unsigned long long *row_ = reinterpret_cast<unsigned long long *>((c)[31]) + \
-    ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * 12; for (int i_ = 0; i_ < 12; i_++) row_[i_] = ph_[i_]; } } while (0)
+    ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; for (int i_ = 0; i_ < 12; i_++) row_[i_] = ph_[i_]; row_[12] = w0_; row_[13] = wall_clock64(); row_[14] = info_; } } while (0)
+#define RT_STAMP_INFO(x) do { info_ = (x); } while (0)
 #else
 #define RT_STAMP_DECL
 #define RT_STAMP(i)
 #define RT_STAMP_FLUSH(c, lane)
+#define RT_STAMP_INFO(x)
 #endif
 // Occupancy target (waves per SIMD) of each instantiation = the highest one at which NOTHING spills to scratch.
 // That is a correctness rule, not tuning: ROCm 7.2's compiler can place a VGPR spill at the top of a join block before
@@ -543,7 +546,7 @@ constexpr int NO_BLOCKER = 0x7fffffff;
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC>
 __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj,
                                               const Mono &sm, double max_t, bool valid, bool prod, const Ball *ballp, const CullRec *crec, const DevLight &lt,
-                                              uint32_t lane, Cnt<COUNT> &cnt)
+                                              bool lt_spherical, uint32_t lane, Cnt<COUNT> &cnt)
 {
     // valid: lanes whose ray is tested.  prod: lanes the product build tests (== valid there); a counting build tests more lanes --
     // all that have a hit -- and counts executed work for the `prod` ones only (wave-level work: if any lane is one).
@@ -555,10 +558,10 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
         const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
         unsigned long long cand = 0;
         if (fa.cull) {
-            unsigned long long it = (base == 0 && !lt.spherical) ? relevant_mask_directional(crec, end, lt, lane) // wave-uniform choice
+            unsigned long long it = (base == 0 && !lt_spherical) ? relevant_mask_directional(crec, end, lt, lane) // wave-uniform choice
                                                                  : relevant_mask(S.us, base, end, *ballp, lt, lane); // (the ball is read from LDS here, not kept)
 
-            if (lane == 0 && prod_any) cnt.cull(lt.spherical ? C_SHADOW_SPH : C_SHADOW_DIR, end - base);
+            if (lane == 0 && prod_any) cnt.cull(lt_spherical ? C_SHADOW_SPH : C_SHADOW_DIR, end - base);
             if (prod) cnt.exec(K_US, (unsigned long long) __popcll(it));
             while (it) { // wave-uniform loop over the spheres that survived the culling
                 const int b = __builtin_ctzll(it);
@@ -696,7 +699,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     uint32_t *s_live = s_wcount + 4;                                  // [4] per-wave "still bouncing" flags
     uint32_t *s_sparse = s_wcount + 8;                                // [1] sparse output: this tile's slot in the message (or none)
 
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // `wave` through readfirstlane: the compiler cannot see that threadIdx.x >> 6 is the same in every lane of a wave, and would otherwise
+    // treat every loop and branch that depends on it (the light loop of phase B, "wave < n_chunks", ...) as divergent
+    const uint32_t tid = threadIdx.x, wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = tid & 63;
     RT_STAMP_DECL
     // No prologue: 83 % of the tiles of a typical frame contain no hit at all, and for those the whole job is
     // "primary rays miss, store the background".  Round 0 therefore reads the (culled, tiny) part of the tables it
@@ -922,6 +927,16 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             lds_barrier(); // s_live[0] is reused by the round loop
         }
 
+        if (covered) return; // workgroup-uniform
+        // A tile that gets here (its word says NONEMPTY, or it passed the tile-level test, or was listed, or the scene has no such
+        // test) will almost surely find hits and stage the scene: request this thread's share of the copy now, in front of the
+        // camera-table reads.  Two 16-byte pieces per thread cover 8 KB of tables + lights; larger scenes copy the rest the ordinary way.
+        const uint4 *stage_scene = reinterpret_cast<const uint4 *>(gscene + fa.off_us);
+        const uint4 *stage_light = reinterpret_cast<const uint4 *>(glight);
+        const uint32_t n16 = fa.stage_bytes / 16, tot16 = n16 + fa.n_lights * (uint32_t) (sizeof(DevLight) / 16);
+        uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
+        if (tid < tot16) pre0 = tid < n16 ? stage_scene[tid] : stage_light[tid - n16];
+        if (tid + WG < tot16) pre1 = tid + WG < n16 ? stage_scene[tid + WG] : stage_light[tid + WG - n16];
         F3 res = bg;
         D3 o{fa.origin[0], fa.origin[1], fa.origin[2]};
 #if RT_WF_CAMTAB
@@ -929,18 +944,18 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
 #else
         D3 dir = primary_dir(fa, (int) xc, (int) y);
 #endif
-        if (covered) return; // workgroup-uniform
-        // A tile that gets here (it passed the tile-level cone test, or was listed, or the scene has no such test) will
-        // almost surely find hits and stage the scene: request this thread's share of the copy now (after the
-        // camera-table reads, so that those can be waited for on their own) and let the latency pass behind phase A
-        // instead of in front of the shadow phase.  Two 16-byte pieces per thread cover 8 KB of tables + lights; larger
-        // scenes copy the rest the ordinary way.
-        const uint4 *stage_scene = reinterpret_cast<const uint4 *>(gscene + fa.off_us);
-        const uint4 *stage_light = reinterpret_cast<const uint4 *>(glight);
-        const uint32_t n16 = fa.stage_bytes / 16, tot16 = n16 + fa.n_lights * (uint32_t) (sizeof(DevLight) / 16);
-        uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
-        if (tid < tot16) pre0 = tid < n16 ? stage_scene[tid] : stage_light[tid - n16];
-        if (tid + WG < tot16) pre1 = tid + WG < n16 ? stage_scene[tid + WG] : stage_light[tid + WG - n16];
+        // All-sphere scenes: only tiles that some sphere reaches into get here (tile words / tile-level test / lists), so the
+        // tables go to LDS BEFORE phase A and round 0 reads them there.  (Reading them from global memory in round 0 -- scalar
+        // loads for the wave-uniform entries -- was the cheap way while most workgroups that got here found their tile empty;
+        // with ~4800 waves starting phase A in the same microsecond it serialised them on the scalar cache: phase A took 5-10 us.)
+        if (ALL_SPHERES_POSSIBLE && fa.all_cullable) { // launch-uniform
+            uint4 *dst = reinterpret_cast<uint4 *>(smem + L.scene);
+            if (tid < tot16) dst[tid] = pre0;
+            if (tid + WG < tot16) dst[tid + WG] = pre1;
+            for (uint32_t i = tid + 2 * WG; i < tot16; i += WG) dst[i] = i < n16 ? stage_scene[i] : stage_light[i - n16];
+            staged = true;
+            lds_barrier();
+        }
         bool live = inside; // this pixel still has a ray to trace
         bool first = true;
         uint32_t ord_cls = 0, ord_pos = 0; // thread 0: this tile's entry in the next frame's launch order
@@ -960,7 +975,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 mono_set_o<NEED_CROSS>(m, o);
                 mono_set_d<NEED_CROSS>(m, dir);
                 mono_set_od<NEED_CROSS>(m);
-                if (first) nearest<COUNT, HAS_GQ, HAS_CUBIC, true>(fa, G, gobj, m, live, lane, best_t, best, cnt);
+                if (first && staged) nearest<COUNT, HAS_GQ, HAS_CUBIC, true>(fa, S, gobj, m, live, lane, best_t, best, cnt);
+                else if (first) nearest<COUNT, HAS_GQ, HAS_CUBIC, true>(fa, G, gobj, m, live, lane, best_t, best, cnt);
                 else nearest<COUNT, HAS_GQ, HAS_CUBIC, false>(fa, S, gobj, m, live, lane, best_t, best, cnt);
             }
             RT_STAMP(2);
@@ -973,7 +989,12 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             D3 sp{0.0, 0.0, 0.0}, sn{0.0, 0.0, 1.0};
             if (hit) {
                 sp = D3{o.x + best_t * dir.x, o.y + best_t * dir.y, o.z + best_t * dir.z};
-                sn = normal_vector(gobj[best].c, sp); // 20 coefficients of the hit object, gathered from global (L2) per hit
+                if (ALL_SPHERES_POSSIBLE && fa.n_us == fa.n_obj) { // launch-uniform: every object is a unit sphere -- table index == object index
+                    if (staged) sn = sphere_normal(S.us[best], sp);  // three coefficients from the table instead of twenty from the object record
+                    else sn = sphere_normal(G.us[best], sp);
+                } else {
+                    sn = normal_vector(gobj[best].c, sp); // 20 coefficients of the hit object, gathered from global (L2) per hit
+                }
                 cnt.add(4);
             }
             // ---------------- compaction of the tile's hits into the LDS queue ----------------
@@ -993,6 +1014,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     ord_pos = atomicAdd(&ord_wr[4u - ord_cls], 1u); // only needed at the very end: the round trip costs nothing
                 }
             }
+            if (first) RT_STAMP_INFO(((unsigned long long) tile << 32) | n_hits);
             if (n_hits == 0) break; // workgroup-uniform: nothing left to shade or bounce (all lanes are dead by now)
             const uint32_t n_chunks = (n_hits + 63) >> 6;
             if (!staged) { // first round with hits: bring the scene and the lights into LDS (one contiguous image), 16 B per lane per step
@@ -1063,6 +1085,10 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 }
                 for (uint32_t l = (wave + 4u - (c & 3u)) & 3u; l < fa.n_lights; l += 4) {
                     const DevLight &lt = S.light[l]; // wave-uniform LDS reads
+                    // (the two flags through readfirstlane: values read from LDS are not known to be uniform, and the branches on them
+                    // would be compiled as divergent ones)
+                    const bool lt_spherical = __builtin_amdgcn_readfirstlane((int) lt.spherical) != 0;
+                    const bool lt_backface_exact = __builtin_amdgcn_readfirstlane((int) lt.backface_exact) != 0;
                     if (valid) cnt.add(1);
                     // A directional light behind the surface contributes exactly +0 whether or not it is shadowed:
                     // surface_color multiplies by max(0.0f, (float) dot(n, light.p)) (include/light_impl.h:43), and the
@@ -1070,7 +1096,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     // hit of the chunk costs nothing beyond this dot product.  (COUNT builds test them anyway: the
                     // reference-equivalent test count needs the index of the first blocker.)
                     bool wanted = valid; // the lanes the product build traces; a counting build traces every hit's ray (it needs the first blocker's index)
-                    if (lt.backface_exact) { // directional, all colours finite (rt_scene_dev.h)
+                    if (lt_backface_exact) { // directional, all colours finite (rt_scene_dev.h)
                         const float lam = (float) dot3(nrm, D3{lt.p[0], lt.p[1], lt.p[2]});
                         wanted = valid && (0.0f < lam);
                         // ... and the shading phase need not look at this light for these hits either: same bit as "blocked"
@@ -1078,7 +1104,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                         if (!COUNT && !__any(wanted)) continue;
                     }
                     double max_t;
-                    if (lt.spherical) {
+                    if (lt_spherical) {
                         // shadow_ray, include/light_impl.h:19-21: (light - point) through FP32
                         max_t = 1.0;
                         const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]}; // re-read: not kept in registers across lights
@@ -1106,7 +1132,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     mono_set_od<NEED_CROSS>(sm);
                     if (wanted) cnt.traced();
                     const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, screc + c * L.n_crec, lt,
-                                                                                 lane, cnt);
+                                                                                 lt_spherical, lane, cnt);
                     if (valid) {
                         // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
                         cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);

@@ -119,6 +119,17 @@ __device__ __forceinline__ void mono_set_od(Mono &m)
     }
 }
 
+// normal_vector (include/surface_impl.h:157-172) of a unit sphere from its table entry.  With x2 = y2 = z2 = 1 and every other
+// coefficient of degree >= 2 exactly zero, each term of the reference's gradient that carries such a coefficient is an exact
+// signed zero, and adding it changes nothing but possibly the sign of a zero component (which no later operation can turn into
+// a different pixel: it only ever multiplies or is added to something); what remains, in the reference's order, is
+// ((2 * 1) * p + k), then the same normalisation.
+__device__ __forceinline__ D3 sphere_normal(const UsEntry &e, const D3 &p)
+{
+    const D3 g{(2.0 * 1.0) * p.x + e.kx, (2.0 * 1.0) * p.y + e.ky, (2.0 * 1.0) * p.z + e.kz};
+    return normalize3(g);
+}
+
 // Nearest-hit rule of src/update-cpu.cpp:52-55 made order-independent: strict '<' with ascending object index
 // means the lowest index wins ties.
 __device__ __forceinline__ void accept(double t, int k, double &best_t, int &best)

@@ -214,6 +214,9 @@ int rt_get_counters_detail(rt_ctx *ctx, rt_counters_detail *out); /* wavefront k
 /* Diagnostics: the raw device counter block (32 words).  Words 0-7 are rt_counters; words 8+ are per-phase
  * wave-cycle totals that only a library built with `make STAMPS=1` fills in. */
 int rt_debug_counters(rt_ctx *ctx, uint64_t out[32]);
+/* Diagnostics (`make STAMPS=1` + MI355RT_DEBUG_COUNTERS=1 only): the last frame's per-wave rows of 16 words -- 0-11 cycles per phase,
+ * 12 / 13 a 100 MHz clock at the wave's start / end; row = workgroup * 4 + wave.  out = NULL: only the row count. */
+int rt_debug_stamp_rows(rt_ctx *ctx, uint64_t *out, size_t max_rows, size_t *n_rows);
 
 /* Replaces cleanup_update (include/update.h:8). */
 int rt_destroy(rt_ctx *ctx);

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""When is the machine busy?  Per-wave start / end times of one frame (diagnostic library: make STAMPS=1 SPILLS_OK=1, run with
+MI355RT_DEBUG_COUNTERS=1): waves alive per microsecond, split by what they end up doing, and the phase shares.
+usage: python tools/timeline.py [W H [flags]]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["MI355RT_DEBUG_COUNTERS"] = "1"
+import __graft_entry__ as graft  # noqa: E402
+
+pkg = graft.load_package()
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 1080
+flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+sc = pkg.Scene.load_from_file(os.path.join(ROOT, "scenes", "20spheres.yml")).set_size(W, H)
+r = pkg.Renderer(sc, device=0, flags=flags)
+for _ in range(4):
+    ms = r.update()
+rows = r.stamp_rows()
+rows = rows[rows[:, 13] > 0]
+t0 = rows[:, 12].min()
+start = (rows[:, 12] - t0).astype(np.float64) / 100.0   # 100 MHz -> us
+end = (rows[:, 13] - t0).astype(np.float64) / 100.0
+traced = rows[:, 6] > 0          # waves that went through the shadow phase
+other = ~traced
+print(f"20spheres {W}x{H} flags={flags}: kernel {ms*1e3:.1f} us (stamped build); {len(rows)} waves wrote a row, {int(traced.sum())} of them traced shadow rays")
+print(f"last wave ends at {end.max():.1f} us; tracing waves: start median {np.median(start[traced]):.1f} us (90 %: {np.percentile(start[traced], 90):.1f}), "
+      f"lifetime median {np.median((end - start)[traced]):.1f} us, max {(end - start)[traced].max():.1f} us")
+step = max(1.0, round(end.max() / 30.0))
+print(f"{'t (us)':>8} {'tracing':>8} {'other':>8}   waves alive (5120 slots)")
+for t in np.arange(0.0, end.max() + step, step):
+    a = int(((start <= t) & (end > t) & traced).sum())
+    b = int(((start <= t) & (end > t) & other).sum())
+    print(f"{t:8.1f} {a:8d} {b:8d}   {'#' * (a // 100)}{'.' * (b // 100)}")
+names = ["stage scene->LDS", "setup/primary dir", "A nearest", "A normal+compact", "barrier after A", "A' balls + barrier",
+         "B shadow items", "barrier after B", "C shade", "D blend + barrier", "store", "classify / paint"]
+tot = rows[:, :12].sum()
+for i, n in enumerate(names):
+    print(f"  {n:22s} {int(rows[:, i].sum()):14d}  {100.0 * rows[:, i].sum() / max(tot, 1):5.1f} %")
+# per workgroup: lifetime against the tile's hit count
+info = rows[:, 14]
+wg = {}
+for i in np.nonzero(traced)[0]:
+    key = int(info[i] >> np.uint64(32))
+    e = wg.setdefault(key, dict(hits=int(info[i] & np.uint64(0xFFFFFFFF)), start=start[i], end=end[i], b=0, a=0, setup=0, c=0))
+    e["start"], e["end"] = min(e["start"], start[i]), max(e["end"], end[i])
+    e["b"] = max(e["b"], int(rows[i, 6])); e["a"] = max(e["a"], int(rows[i, 2])); e["setup"] = max(e["setup"], int(rows[i, 1])); e["c"] = max(e["c"], int(rows[i, 8]))
+life = np.array([v["end"] - v["start"] for v in wg.values()])
+hits = np.array([v["hits"] for v in wg.values()])
+bcyc = np.array([v["b"] for v in wg.values()], dtype=np.float64)
+print(f"{len(wg)} tracing workgroups; lifetime by round-0 hits:")
+for lo, hi in ((1, 64), (65, 128), (129, 192), (193, 255), (256, 256)):
+    m = (hits >= lo) & (hits <= hi)
+    if m.any():
+        print(f"  hits {lo:3d}-{hi:3d}: {int(m.sum()):5d} tiles, lifetime median {np.median(life[m]):5.1f} us, 90 % {np.percentile(life[m], 90):5.1f}, max {life[m].max():5.1f};"
+              f" longest wave's shadow phase median {np.median(bcyc[m]) / 2400.0:5.1f} us (at 2.4 GHz), max {bcyc[m].max() / 2400.0:5.1f}")
+order = np.argsort(-life)[:12]
+keys = list(wg.keys())
+print("longest tiles: tile, hits, lifetime us, setup / A / B / C of its slowest wave (us at 2.4 GHz)")
+for j in order:
+    v = wg[keys[j]]
+    print(f"  tile {keys[j]:5d} hits {v['hits']:3d} life {life[j]:5.1f}  setup {v['setup']/2400.0:4.1f} A {v['a']/2400.0:4.1f} B {v['b']/2400.0:5.1f} C {v['c']/2400.0:4.1f}")

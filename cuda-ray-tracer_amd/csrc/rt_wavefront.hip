@@ -102,7 +102,8 @@ constexpr int wf_occupancy()
 {
     int occ = HAS_CUBIC ? 2 : (HAS_MIRROR ? (HAS_GQ ? 3 : 4) : (HAS_GQ ? 3 : 5)); // 95 / 128 / 168 / ~200 VGPRs (strict, no counters); the
                                                                                   // mirror-free general-quadric one needs 129-130 at 4
-    if (!HAS_CUBIC && (COUNT || RT_FAST)) occ -= 1; // counters / the FMA build's different schedule need a few registers more
+    if (!HAS_CUBIC && RT_FAST && !COUNT) occ -= 1;  // the FMA build's different schedule needs a few registers more
+    if (!HAS_CUBIC && COUNT) occ -= 2;              // 8 + 18 counters in registers; counting renders are not timed
     if (HAS_CUBIC && COUNT) occ = 1;                // counting builds inline the cubic path (they report its solver branch)
     if (!HAS_CUBIC && COUNT && RT_FAST && HAS_MIRROR) occ -= 1;
     occ += RT_WF_OCC_DELTA;
@@ -499,16 +500,19 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
     }
 }
 
+template <bool SPHERICAL>
 __device__ __forceinline__ unsigned long long relevant_mask(const UsEntry *us, uint32_t base, uint32_t end, const Ball &ball,
                                                             const DevLight &lt, uint32_t lane)
 {
     const uint32_t j = base + lane;
-    return __ballot(j < end && sphere_relevant(us[j], ball, lt));
+    return __ballot(j < end && sphere_relevant<SPHERICAL>(us[j], ball, lt));
 }
 
-__device__ __forceinline__ unsigned long long relevant_mask_directional(const CullRec *crec, uint32_t end, const DevLight &lt, uint32_t lane)
+// directional lights, first group of spheres: from the chunk's culling records; the light's direction is the ray direction the
+// caller already holds (include/light_impl.h:23-25: the same for every hit)
+__device__ __forceinline__ unsigned long long relevant_mask_directional(const CullRec *crec, uint32_t end, const D3 &sdir, double inv_uu, double len_u, uint32_t lane)
 {
-    return __ballot(lane < end && crec_relevant(crec[lane], lt));
+    return __ballot(lane < end && crec_relevant(crec[lane], sdir, inv_uu, len_u));
 }
 
 constexpr uint32_t CREC_MAX = 64; // culling records cover the first group of 64 spheres; further groups take relevant_mask
@@ -543,10 +547,10 @@ constexpr int NO_BLOCKER = 0x7fffffff;
 
 // Phase B for one (chunk, light) item: is the lane's shadow ray blocked, and (COUNT builds) by which lowest
 // object index.  `blocker` keeps the lowest blocking index seen; without COUNT any blocker ends the search.
-template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC>
+template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool SPHERICAL> // SPHERICAL: the light's kind -- one copy of the loop per kind, each without the other's code
 __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj,
                                               const Mono &sm, double max_t, bool valid, bool prod, const Ball *ballp, const CullRec *crec, const DevLight &lt,
-                                              bool lt_spherical, uint32_t lane, Cnt<COUNT> &cnt)
+                                              uint32_t lane, Cnt<COUNT> &cnt)
 {
     // valid: lanes whose ray is tested.  prod: lanes the product build tests (== valid there); a counting build tests more lanes --
     // all that have a hit -- and counts executed work for the `prod` ones only (wave-level work: if any lane is one).
@@ -558,10 +562,10 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
         const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
         unsigned long long cand = 0;
         if (fa.cull) {
-            unsigned long long it = (base == 0 && !lt_spherical) ? relevant_mask_directional(crec, end, lt, lane) // wave-uniform choice
-                                                                 : relevant_mask(S.us, base, end, *ballp, lt, lane); // (the ball is read from LDS here, not kept)
-
-            if (lane == 0 && prod_any) cnt.cull(lt_spherical ? C_SHADOW_SPH : C_SHADOW_DIR, end - base);
+            unsigned long long it;
+            if (!SPHERICAL && base == 0) it = relevant_mask_directional(crec, end, sm.d, lt.inv_uu, lt.len_u, lane); // sm.d is this light's FP32-rounded direction
+            else it = relevant_mask<SPHERICAL>(S.us, base, end, *ballp, lt, lane); // (the ball is read from LDS here, not kept)
+            if (lane == 0 && prod_any) cnt.cull(SPHERICAL ? C_SHADOW_SPH : C_SHADOW_DIR, end - base);
             if (prod) cnt.exec(K_US, (unsigned long long) __popcll(it));
             while (it) { // wave-uniform loop over the spheres that survived the culling
                 const int b = __builtin_ctzll(it);
@@ -1131,8 +1135,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     }
                     mono_set_od<NEED_CROSS>(sm);
                     if (wanted) cnt.traced();
-                    const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, screc + c * L.n_crec, lt,
-                                                                                 lt_spherical, lane, cnt);
+                    const int blocker = lt_spherical
+                        ? shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, true>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, screc + c * L.n_crec, lt, lane, cnt)
+                        : shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, false>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, screc + c * L.n_crec, lt, lane, cnt);
                     if (valid) {
                         // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
                         cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);

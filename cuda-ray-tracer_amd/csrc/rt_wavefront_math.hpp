@@ -238,6 +238,7 @@ struct Ball {
     double cx, cy, cz, R;
 };
 
+template <bool SPHERICAL> // the light's kind, known to the caller (wave-uniform): only that half is compiled into the loop
 __device__ __forceinline__ bool sphere_relevant(const UsEntry &e, const Ball &ball, const DevLight &lt)
 {
     bool rel = false;
@@ -250,7 +251,7 @@ __device__ __forceinline__ bool sphere_relevant(const UsEntry &e, const Ball &ba
         const double ww = wx * wx + wy * wy + wz * wz;
         const double w1 = fabs(wx) + fabs(wy) + fabs(wz); // >= |w|
         const double s2 = ccx * ccx + ccy * ccy + ccz * ccz + ball.cx * ball.cx + ball.cy * ball.cy + ball.cz * ball.cz;
-        if (!lt.spherical) {
+        if (!SPHERICAL) {
             const double along = wx * lt.sdir[0] + wy * lt.sdir[1] + wz * lt.sdir[2];
             const double perp2 = ww - along * along * lt.inv_uu;
             const double lim = r + ball.R + 1e-6 * (w1 + r + ball.R + 1.0) + 1e-12 * (s2 + 1.0) * e.inv_r;
@@ -297,11 +298,11 @@ __device__ __forceinline__ CullRec cull_record(const UsEntry &e, const Ball &bal
     return c;
 }
 
-__device__ __forceinline__ bool crec_relevant(const CullRec &c, const DevLight &lt)
+__device__ __forceinline__ bool crec_relevant(const CullRec &c, const D3 &sdir, double inv_uu, double len_u)
 {
-    const double along = c.wx * lt.sdir[0] + c.wy * lt.sdir[1] + c.wz * lt.sdir[2];
-    const double perp2 = c.ww - along * along * lt.inv_uu;
-    return !(perp2 > c.lim * c.lim) && !(along < -c.lim * lt.len_u);
+    const double along = c.wx * sdir.x + c.wy * sdir.y + c.wz * sdir.z;
+    const double perp2 = c.ww - along * along * inv_uu;
+    return !(perp2 > c.lim * c.lim) && !(along < -c.lim * len_u);
 }
 
 __device__ __forceinline__ void blend(F3 &res, float ratio, const F3 &c)
@@ -313,6 +314,5 @@ __device__ __forceinline__ void blend(F3 &res, float ratio, const F3 &c)
 }
 
 __host__ __device__ inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
-
 
 } // namespace rtm

@@ -119,8 +119,8 @@ int main()
     const Ball ball{1.0, 0.4, 8.0, 0.2};
     CullRec rec;
     const long cull_record_ops = ops([&] { rec = cull_record(us, ball); });
-    const long cull_shadow_directional = ops([&] { g_sink = crec_relevant(rec, dir_light); });
-    const long cull_shadow_point = ops([&] { g_sink = sphere_relevant(us, ball, pt_light); });
+    const long cull_shadow_directional = ops([&] { g_sink = crec_relevant(rec, D3{dir_light.sdir[0], dir_light.sdir[1], dir_light.sdir[2]}, dir_light.inv_uu, dir_light.len_u); });
+    const long cull_shadow_point = ops([&] { g_sink = sphere_relevant<true>(us, ball, pt_light); });
     // --- rays
     const long primary_dir_ops = ops([&] { D3 dd = primary_dir_tab(fa, 0.05, -0.02); g_sink = dd.x > 0.0; });
     const long cone_axis_dot = ops([&] { g_sink = dot3(axis, d) > 0.0; });

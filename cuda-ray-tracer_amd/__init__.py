@@ -108,6 +108,9 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, dp, fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
         L.rt_abi_version.restype = C.c_int
+        if (L.rt_abi_version() & 0x4000) and not os.environ.get("MI355RT_ALLOW_DIAGNOSTIC"):
+            raise RtError(-3, f"{LIB_PATH} is a diagnostic build (make STAMPS=1 / DEBUG_EXITS=1 / SPILLS_OK=1 ...), not the product: rebuild with plain "
+                              "`make`, or set MI355RT_ALLOW_DIAGNOSTIC=1 for a measurement")
         L.rt_last_error.restype = C.c_char_p
         L.rt_scene_load_file.argtypes = [C.c_char_p, C.POINTER(vp)]
         L.rt_scene_new.argtypes = [C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, fp, C.POINTER(vp)]

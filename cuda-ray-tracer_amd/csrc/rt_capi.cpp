@@ -99,6 +99,9 @@ struct rt_ctx {
     void *d_fb = nullptr;
     unsigned long long *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_done = nullptr;      // recorded behind every render: a render on ANOTHER stream waits for it (frames of a context are ordered)
+    hipStream_t last_stream = nullptr;
+    bool rendered = false;
     bool counted = false;
     bool zero_counters = false; // diagnostic builds: clear counters[] before every render
     uint64_t *d_stamps = nullptr;
@@ -111,7 +114,11 @@ struct rt_ctx {
 };
 
 // ---------------------------------------------------------------------------------------------------
+#ifdef RT_DIAGNOSTIC_BUILD
+extern "C" int rt_abi_version(void) { return RT_ABI_VERSION | RT_ABI_DIAGNOSTIC; } // stamps / experiment exits / spills allowed: not the product
+#else
 extern "C" int rt_abi_version(void) { return RT_ABI_VERSION; }
+#endif
 
 extern "C" const char *rt_last_error(void) { return g_last_error.c_str(); }
 
@@ -334,7 +341,13 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
     if (device >= ndev) return fail(RT_ERR_INVALID, "rt_create: device %d out of range (%d devices)", device, ndev);
     RT_HIP(hipSetDevice(device));
 
-    rt_ctx *ctx = new (std::nothrow) rt_ctx();
+    // owned by a guard until the very end: whatever throws or fails on the way (host-side packing allocates), rt_destroy releases
+    // the context and every device buffer it already holds
+    struct Guard {
+        rt_ctx *p;
+        ~Guard() { if (p) { std::string keep = g_last_error; rt_destroy(p); g_last_error = keep; } }
+    } guard{new (std::nothrow) rt_ctx()};
+    rt_ctx *ctx = guard.p;
     if (!ctx) return fail(RT_ERR_NOMEM, "out of memory");
     ctx->device = device;
     ctx->cfg = cfg;
@@ -480,7 +493,6 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
     }
 
     if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u) > 160u * 1024u) {
-        delete ctx;
         return fail(RT_ERR_SCENE, "rt_create: scene needs %zu bytes of LDS per workgroup (limit 160 KiB)",
                     rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u));
     }
@@ -497,13 +509,9 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
         hip_ok(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * 64), "hipMemset(counters)") &&
         hip_ok(hipMemcpy(ctx->d_obj, blob.data(), blob.size(), hipMemcpyHostToDevice), "hipMemcpy(scene)") &&
         hip_ok(lights.empty() ? hipSuccess : hipMemcpy(ctx->d_light, lights.data(), sizeof(DevLight) * lights.size(), hipMemcpyHostToDevice), "hipMemcpy(lights)") &&
-        hip_ok(hipEventCreate(&ctx->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&ctx->ev1), "hipEventCreate");
-    if (rc != RT_OK) {
-        std::string keep = g_last_error;
-        rt_destroy(ctx);
-        g_last_error = keep;
-        return rc;
-    }
+        hip_ok(hipEventCreate(&ctx->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&ctx->ev1), "hipEventCreate") &&
+        hip_ok(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming), "hipEventCreate");
+    if (rc != RT_OK) return rc;
     {
         // camera-plane coordinates of every pixel column / row: render_pixel's camera_x / camera_y
         // (src/update-cpu.cpp:84-87) depend only on the pixel index and the scene, so they are evaluated here once,
@@ -546,12 +554,7 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
             hip_ok(hipMalloc((void **) &fa.tile_state, sizeof(uint32_t) * fa.n_tiles), "hipMalloc(tile state)") &&
                 hip_ok(hipMemset(fa.tile_state, 0, sizeof(uint32_t) * fa.n_tiles), "hipMemset(tile state)");
         }
-        if (rc != RT_OK) {
-            std::string keep = g_last_error;
-            rt_destroy(ctx);
-            g_last_error = keep;
-            return rc;
-        }
+        if (rc != RT_OK) return rc;
     }
     ctx->zero_counters = std::getenv("MI355RT_DEBUG_COUNTERS") != nullptr;
     if (ctx->zero_counters) { // room for the stamp rows of a diagnostic (STAMPS=1) build: one per wave
@@ -559,6 +562,7 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
         if (hipMalloc((void **) &ctx->d_stamps, ctx->n_stamp_rows * 16 * sizeof(uint64_t) + 8) != hipSuccess) ctx->d_stamps = nullptr;
         else (void) hipMemset(ctx->d_stamps, 0, ctx->n_stamp_rows * 16 * sizeof(uint64_t));
     }
+    guard.p = nullptr;
     *out = ctx;
     return RT_OK;
 }
@@ -596,6 +600,10 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
     RT_HIP(hipGetDevice(&cur));
     if (cur != ctx->device) RT_HIP(hipSetDevice(ctx->device));
 
+    // A context's frames depend on each other on the device (launch-order generations: read k, append k + 1, clear k + 2; tile words
+    // tagged per frame), so they must run in the order they were issued.  On one stream they do; when the caller switches streams,
+    // the new stream first waits for the previous frame.
+    if (ctx->rendered && stream != ctx->last_stream) RT_HIP(hipStreamWaitEvent(stream, ctx->ev_done, 0));
     void *fb = dev_fb ? dev_fb : ctx->d_fb;
     if (sparse) RT_HIP(hipMemsetAsync(fb, 0, 16, stream)); // message header: count, overflow
     const int count = (ctx->cfg.flags & RT_FLAG_COUNT) ? 1 : 0;
@@ -649,6 +657,9 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
                  : rt_launch_wavefront_strict(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, count, ctx->d_camx, ctx->d_camy, stream);
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     ctx->counted = count != 0;
+    RT_HIP(hipEventRecord(ctx->ev_done, stream));
+    ctx->last_stream = stream;
+    ctx->rendered = true;
     if (ms) {
         RT_HIP(hipEventRecord(ctx->ev1, stream));
         RT_HIP(hipEventSynchronize(ctx->ev1));
@@ -853,6 +864,7 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     if (ctx->h_listed) (void) hipHostFree(ctx->h_listed);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
+    if (ctx->ev_done) (void) hipEventDestroy(ctx->ev_done);
     delete ctx;
     return RT_OK;
 }

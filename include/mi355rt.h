@@ -24,6 +24,8 @@ extern "C" {
 #endif
 
 #define RT_ABI_VERSION 2
+#define RT_ABI_DIAGNOSTIC 0x4000 /* set in rt_abi_version() of a library built with STAMPS / DEBUG_EXITS / SPILLS_OK / ...: for
+                                    measurements only (it may spill registers to scratch, which the product never does) */
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -163,10 +165,11 @@ int rt_create(rt_ctx **out, const rt_scene_desc *scene, const rt_config *cfg);
  *   ms      if non-NULL: the call synchronises and stores the device time of the render kernels in
  *           milliseconds (hipEvent pair, what the reference's update() returns); if NULL the call only
  *           enqueues work.
- * A context carries a little state from frame to frame (which tiles had hits: the next frame starts those first;
- * it affects speed only).  Issue a context's frames in order, on one stream at a time; each call passes new
- * arguments, so replaying a captured graph of it renders correctly but without that ordering (use
- * RT_FLAG_STATIC_ORDER for contexts that are captured). */
+ * A context carries state from frame to frame on the device (which tiles had hits: the next frame starts those first; per-frame
+ * tile words), so its frames run in the order they were issued: on one stream that is automatic, and when a call passes a
+ * different stream than the previous one, that stream first waits for the previous frame (an event recorded behind every
+ * render).  The state affects speed only, never the image.  Each call passes new arguments, so replaying a captured graph of
+ * it renders correctly but without the ordering (use RT_FLAG_STATIC_ORDER for contexts that are captured). */
 int rt_render(rt_ctx *ctx, const double cam[16], void *dev_fb, void *stream, float *ms);
 
 /* Row ownership: number of local rows, and for local row i its global y (row 0 = bottom of the image,

@@ -698,3 +698,23 @@ def test_incremental_sparse_assembly_follows_a_moving_camera(pkg):
         assert np.array_equal(full.cpu().numpy(), want), f"frame {k}"
         saw_content += int(msgs.cpu().numpy().view(np.uint32)[:, 0].sum() > 0)
     assert 3 <= saw_content < len(cams)   # the sequence really has frames with and without content
+
+
+def test_frames_issued_on_alternating_streams(pkg):
+    """A context's frames depend on each other on the device (launch-order generations, tile words): rt_render orders a frame
+    behind the previous one when the caller switches streams.  Eight frames of a moving camera, alternately on two streams,
+    no host synchronisation in between; every frame equals an index-order context's frame."""
+    import torch
+    w, h = 640, 360
+    sc = random_scene(pkg, 4242, 40, 6, w=w, h=h, with_plane=False)
+    r = pkg.Renderer(sc, device=0)
+    ref = pkg.Renderer(sc, device=0, flags=pkg.RT_FLAG_STATIC_ORDER | pkg.RT_FLAG_NOSCAN)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bufs = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0") for _ in range(8)]
+    cams = [pkg.camera_matrix((0.3 * k, 0.1 * k, -0.5 * k), 90.0 + 5.0 * (k % 3) - (180.0 if k == 4 else 0.0), 1.0 * k) for k in range(8)]
+    for k, cam in enumerate(cams):
+        r.update(cam, dev_fb=bufs[k].data_ptr(), stream=streams[k & 1].cuda_stream, timed=False)
+    torch.cuda.synchronize()
+    for k, cam in enumerate(cams):
+        ref.update(cam)
+        assert np.array_equal(bufs[k].cpu().numpy(), ref.download()), k

@@ -114,6 +114,12 @@ ERRORS = [
     (BASE.replace("    direction: [0, -1, 0]\n", ""), "Value 'direction' undefined, line: 8 column: 5"),
     (BASE + "    intensity: -2\n", "Negative value for light intensity: -2"),
     (BASE.replace("fov: 90", "bg_color: [0, 2, 0]\nfov: 90"), "Invalid color: (0, 2, 0)"),
+    # a mandatory vector with an element that is not a number: the reference reports the key with the ELEMENT's mark (get_value catches the
+    # BadConversion thrown by the inner as<T>() of the vec3 converter, src/scene.cpp:48-53,84-92)
+    (BASE.replace("color: [1, 0, 0]", "color: [1, red, 0]"), "Value 'color' is invalid, line: 6 column: 16"),
+    (BASE.replace("direction: [0, -1, 0]", "direction: [0, -1, down]"), "Value 'direction' is invalid, line: 9 column: 24"),
+    # the same in an OPTIONAL key: the reference lets yaml-cpp's exception escape (uncaught: the program terminates); here a SceneException
+    (BASE.replace("type: sphere", "type: sphere\n    center: [0, x, 0]"), "Vector component of 'center' is invalid, line: 6 column: 17"),
     ("width: 8\n\theight: 4\n", "YAML parser error: yaml-subset: error at line 2, column 1: tab characters are not allowed as indentation"),
     ("width: [1, 2\n", "YAML parser error: yaml-subset: error at line 1, column 8: unterminated flow sequence"),
     ("width: &a 8\n", "YAML parser error: yaml-subset: error at line 1, column 8: unsupported YAML construct '&'"),

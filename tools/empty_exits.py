@@ -5,6 +5,7 @@ the barrier (no paint).  Frames are wrong by construction; only the times matter
 import os
 import subprocess
 import sys
+os.environ["MI355RT_ALLOW_DIAGNOSTIC"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)

@@ -10,6 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["MI355RT_DEBUG_COUNTERS"] = "1"
+os.environ["MI355RT_ALLOW_DIAGNOSTIC"] = "1"
 import __graft_entry__ as graft  # noqa: E402
 
 pkg = graft.load_package()

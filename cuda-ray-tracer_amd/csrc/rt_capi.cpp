@@ -807,7 +807,7 @@ extern "C" int rt_get_counters_detail(rt_ctx *ctx, rt_counters_detail *out)
     if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_get_counters_detail: null argument");
     if (!ctx->counted) return fail(RT_ERR_INVALID, "rt_get_counters_detail: the last render was not done with RT_FLAG_COUNT");
     if (ctx->cfg.flags & RT_FLAG_SIMPLE) return fail(RT_ERR_INVALID, "rt_get_counters_detail: the simple kernel does not split its counters");
-    unsigned long long h[18];
+    unsigned long long h[19];
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipDeviceSynchronize());
     RT_HIP(hipMemcpy(h, ctx->d_counters + 32, sizeof(h), hipMemcpyDeviceToHost));
@@ -817,6 +817,7 @@ extern "C" int rt_get_counters_detail(rt_ctx *ctx, rt_counters_detail *out)
     for (int i = 0; i < 4; i++) out->cubic_branch[i] = h[12 + i];
     out->shadow_rays_traced = h[16];
     out->hit_lights_shaded = h[17];
+    out->primary_rays_formed = h[18];
     return RT_OK;
 }
 

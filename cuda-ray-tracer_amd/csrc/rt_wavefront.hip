@@ -122,9 +122,10 @@ constexpr int wf_occupancy()
 //             32-35 tests executed per surface class (unit sphere, other quadric, plane, cubic)   36-38 root solves per class
 //             39-43 culling: tile pyramid, primary cone, shadow phase directional / point light, records formed
 //             44-47 cubic tests by solver branch   48 shadow rays traced (of counters[1] considered)   49 hits shaded per light
+//             50 primary rays formed (pixels of the tiles that are traced; counters[0] counts every pixel, as the reference does)
 enum { K_US = 0, K_GQ = 1, K_LIN = 2, K_CUB = 3 };
 enum { C_TILE = 0, C_PRIMARY = 1, C_SHADOW_DIR = 2, C_SHADOW_SPH = 3, C_RECORDS = 4 };
-constexpr int N_CNT_W = 18;
+constexpr int N_CNT_W = 19;
 template <bool COUNT>
 struct Cnt {
     __device__ __forceinline__ void add(int, unsigned long long = 1) {}
@@ -134,12 +135,13 @@ struct Cnt {
     __device__ __forceinline__ void cubic(int, bool = true) {}
     __device__ __forceinline__ void traced() {}
     __device__ __forceinline__ void shaded() {}
+    __device__ __forceinline__ void primary_traced() {}
     __device__ __forceinline__ void flush(unsigned long long *) {}
 };
 template <>
 struct Cnt<true> {
     unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t w[N_CNT_W] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // per thread and frame: 32 bits are plenty
+    uint32_t w[N_CNT_W] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // per thread and frame: 32 bits are plenty
     __device__ __forceinline__ void add(int i, unsigned long long n = 1) { v[i] += n; }
     __device__ __forceinline__ void exec(int cls, unsigned long long n) { v[6] += n; w[cls] += (uint32_t) n; }
     __device__ __forceinline__ void solve(int cls) { v[5] += 1; w[4 + cls] += 1; }
@@ -152,6 +154,7 @@ struct Cnt<true> {
     }
     __device__ __forceinline__ void traced() { w[16] += 1; }
     __device__ __forceinline__ void shaded() { w[17] += 1; }
+    __device__ __forceinline__ void primary_traced() { w[18] += 1; }
     __device__ __forceinline__ void flush(unsigned long long *g)
     {
         for (int i = 0; i < 8; i++)
@@ -968,6 +971,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         float cur_ratio = 1.0f;
         uint32_t n_refl = 0;
         if (inside) cnt.add(0);
+        cnt.primary_traced(); // every lane of a tracing workgroup forms a primary ray (lanes outside the image a clamped one)
 
         RT_STAMP(1);
         for (;;) { // ----------------------- rounds -----------------------

@@ -111,6 +111,7 @@ typedef struct rt_counters_detail {
     uint64_t cubic_branch[4];   /* cubic tests by solver branch: Cardano, trigonometric, quadratic, linear / none (surface_impl.h:106-154) */
     uint64_t shadow_rays_traced; /* of rt_counters.shadow_rays: those not skipped because the hit faces away from the light */
     uint64_t hit_lights_shaded;  /* surface_color evaluations (light_impl.h:29) */
+    uint64_t primary_rays_formed; /* pixels of the tiles that are actually traced (rt_counters.primary_rays counts every pixel) */
 } rt_counters_detail;
 
 typedef struct rt_ctx rt_ctx;

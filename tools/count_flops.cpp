@@ -14,7 +14,7 @@
 #include <cstring>
 #include <type_traits>
 
-static long g_ops = 0, g_special = 0;
+static long g_ops = 0, g_special = 0, g_div = 0, g_sqrt = 0;
 
 struct Counted {
     double v;
@@ -27,11 +27,11 @@ struct Counted {
     Counted &operator+=(const Counted &o) { g_ops++; v += o.v; return *this; }
     Counted &operator-=(const Counted &o) { g_ops++; v -= o.v; return *this; }
     Counted &operator*=(const Counted &o) { g_ops++; v *= o.v; return *this; }
-    Counted &operator/=(const Counted &o) { g_ops++; v /= o.v; return *this; }
+    Counted &operator/=(const Counted &o) { g_ops++; g_div++; v /= o.v; return *this; }
     friend Counted operator+(const Counted &a, const Counted &b) { g_ops++; return Counted(a.v + b.v); }
     friend Counted operator-(const Counted &a, const Counted &b) { g_ops++; return Counted(a.v - b.v); }
     friend Counted operator*(const Counted &a, const Counted &b) { g_ops++; return Counted(a.v * b.v); }
-    friend Counted operator/(const Counted &a, const Counted &b) { g_ops++; return Counted(a.v / b.v); }
+    friend Counted operator/(const Counted &a, const Counted &b) { g_ops++; g_div++; return Counted(a.v / b.v); }
     friend Counted operator-(const Counted &a) { return Counted(-a.v); }
     friend bool operator<(const Counted &a, const Counted &b) { return a.v < b.v; }
     friend bool operator>(const Counted &a, const Counted &b) { return a.v > b.v; }
@@ -41,7 +41,7 @@ struct Counted {
     friend bool operator!=(const Counted &a, const Counted &b) { return a.v != b.v; }
 };
 static_assert(sizeof(Counted) == 8, "layout of the scene records must not change");
-inline Counted sqrt(const Counted &a) { g_ops++; return Counted(std::sqrt(a.v)); }
+inline Counted sqrt(const Counted &a) { g_ops++; g_sqrt++; return Counted(std::sqrt(a.v)); }
 inline Counted fabs(const Counted &a) { return Counted(std::fabs(a.v)); }
 inline Counted cbrt(const Counted &a) { g_special++; return Counted(std::cbrt(a.v)); }
 inline Counted acos(const Counted &a) { g_special++; return Counted(std::acos(a.v)); }
@@ -53,13 +53,18 @@ inline Counted cos(const Counted &a) { g_special++; return Counted(std::cos(a.v)
 
 using namespace rtm;
 
+static long g_last_div = 0, g_last_sqrt = 0;
 template <typename F>
 static long ops(F f)
 {
-    const long before = g_ops;
+    const long before = g_ops, d0 = g_div, s0 = g_sqrt;
     f();
+    g_last_div = g_div - d0;
+    g_last_sqrt = g_sqrt - s0;
     return g_ops - before;
 }
+struct DS { double div, sqrt; };
+static DS last() { return DS{(double) g_last_div, (double) g_last_sqrt}; }
 
 static volatile bool g_sink;
 
@@ -102,20 +107,28 @@ int main()
     // --- root solves.  The deferred solve re-forms the coefficients from the table entry (second pass over the few candidates).
     auto quad_first = [&] { return ops([&] { g_sink = solve_quadlin(1.0, -10.0, 9.0) > 0.0; }); };   // first root accepted
     auto quad_second = [&] { return ops([&] { g_sink = solve_quadlin(1.0, 10.0, -9.0) > 0.0; }); };  // first root < EPS: second division
-    const double solve_quadlin_mean = 0.5 * (quad_first() + quad_second());
+    const long qf = quad_first(); const DS qf_ds = last(); const long qs = quad_second(); const DS qs_ds = last();
+    const double solve_quadlin_mean = 0.5 * (qf + qs);
+    const DS solve_ds{0.5 * (qf_ds.div + qs_ds.div), 0.5 * (qf_ds.sqrt + qs_ds.sqrt)};
     const long recompute_us = ops([&] { Counted a = us_t1(us, m), b = us_t0(us, m); g_sink = a > b; });
     const long recompute_gq = ops([&] { Counted a = gq_t2(gq, mc), b = gq_t1(gq, mc), c = gq_t0(gq, mc); g_sink = a > b && b > c; });
     const long solve_linear = ops([&] { Counted t = -t0 / t1; g_sink = t > 0.0; });
+    const DS lin_ds = last();
     const long sp0 = g_special;
     const long solve_cardano = ops([&] { g_sink = solve_cubic(1.0, 0.0, 1.0, 1.0) > 0.0; });          // delta > 0
+    const DS cardano_ds = last();
     const long special_cardano = g_special - sp0;
     const long sp1 = g_special;
     const long solve_trig = ops([&] { g_sink = solve_cubic(1.0, 0.0, -3.0, 1.0) > 0.0; });            // three real roots
+    const DS trig_ds = last();
     const long special_trig = g_special - sp1;
     // --- culling decisions (one lane each)
     const D3 org{0.1, 0.2, 0.3}, axis{0.0, 0.0, 1.0};
     const long cull_primary = ops([&] { g_sink = sphere_in_cone(us.kx, us.ky, us.kz, us.r, us.inv_r, org, axis, 0.999); });
-    const long cull_tile = ops([&] { TilePlanes P = tile_planes(fa, -0.1, 0.1, -0.1, 0.1); g_sink = sphere_in_pyramid(us.kx, us.ky, us.kz, us.r, us.inv_r, org, P); });
+    const DS cone_ds = last();
+    TilePlanes P;
+    const long tile_planes_ops = ops([&] { P = tile_planes(fa, -0.1, 0.1, -0.1, 0.1); });   // once per classifying lane (a tile and n_us / 4 spheres)
+    const long cull_tile = ops([&] { g_sink = sphere_in_pyramid(us.kx, us.ky, us.kz, us.r, us.inv_r, org, P); });
     const Ball ball{1.0, 0.4, 8.0, 0.2};
     CullRec rec;
     const long cull_record_ops = ops([&] { rec = cull_record(us, ball); });
@@ -123,6 +136,7 @@ int main()
     const long cull_shadow_point = ops([&] { g_sink = sphere_relevant<true>(us, ball, pt_light); });
     // --- rays
     const long primary_dir_ops = ops([&] { D3 dd = primary_dir_tab(fa, 0.05, -0.02); g_sink = dd.x > 0.0; });
+    const DS pdir_ds = last();
     const long cone_axis_dot = ops([&] { g_sink = dot3(axis, d) > 0.0; });
     const long backface_dot = ops([&] { g_sink = dot3(d, D3{dir_light.p[0], dir_light.p[1], dir_light.p[2]}) > 0.0; });
     const long point_backface = ops([&] {   // rt_wavefront.hip phase B, point light: l - p, q = n.(l - p), |.| sum, FP32 round trip of the direction
@@ -133,12 +147,15 @@ int main()
     });
     const long hit_point = ops([&] { D3 sp{o.x + t1 * d.x, o.y + t1 * d.y, o.z + t1 * d.z}; g_sink = sp.x > 0.0; });
     const long normal_ops = ops([&] { D3 n = normal_vector(cub, o); g_sink = n.x > 0.0; });
+    const DS normal_ds = last();
+    const long sphere_normal_ops = ops([&] { D3 n = sphere_normal(us, o); g_sink = n.x > 0.0; }); // scenes of unit spheres only
     const long bias_ops = ops([&] { D3 b{o.x + SHADOW_BIAS * d.x, o.y + SHADOW_BIAS * d.y, o.z + SHADOW_BIAS * d.z}; g_sink = b.x > 0.0; });
     const long reflect_ops = ops([&] { D3 r = reflect_ray(d, D3{0.0, 1.0, 0.0}); g_sink = r.x > 0.0; });
     const F3 aop{0.2f, 0.2f, 0.2f};
     const float lc[3] = {1.0f, 1.0f, 1.0f};
     const long shade_directional = ops([&] { F3 c = surface_color_pre(dir_light.p, lc, false, o, d, aop); g_sink = c.x > 0.0f; });
     const long shade_point = ops([&] { F3 c = surface_color_pre(pt_light.p, lc, true, o, d, aop); g_sink = c.x > 0.0f; });
+    const DS shade_pt_ds = last();
     const long ball_ops = 3 + 3 + 5 + 1 + 2 + 1; // rt_wavefront.hip phase A': extents (3 sub), centre (3 add 3 mul -> 6; counted 3 + 3), diagonal (3 mul 2 add), sqrt, scale + bias
 
     std::printf("{\n \"source\": \"tools/count_flops.cpp: the kernel's math headers (rt_math.hpp, rt_wavefront_math.hpp) executed over an operation-counting scalar; "
@@ -146,16 +163,28 @@ int main()
     std::printf("  \"test_unitsq\": %ld,\n  \"test_quadric\": %ld,\n  \"test_linear\": %ld,\n  \"test_cubic_expand\": %ld,\n", test_unitsq, test_quadric, test_linear, test_cubic_expand);
     std::printf("  \"solve_unitsq\": %.1f,\n  \"solve_quadric\": %.1f,\n  \"solve_linear\": %ld,\n", recompute_us + solve_quadlin_mean, recompute_gq + solve_quadlin_mean, solve_linear);
     std::printf("  \"cubic_cardano\": %ld,\n  \"cubic_trig\": %ld,\n  \"cubic_quadratic\": %.1f,\n  \"cubic_linear\": %ld,\n", solve_cardano, solve_trig, solve_quadlin_mean, solve_linear);
+    std::printf("  \"tile_planes\": %ld,\n", tile_planes_ops);
     std::printf("  \"cull_tile\": %ld,\n  \"cull_primary\": %ld,\n  \"cull_shadow_directional\": %ld,\n  \"cull_shadow_point\": %ld,\n  \"cull_record\": %ld,\n", cull_tile, cull_primary,
                 cull_shadow_directional, cull_shadow_point, cull_record_ops);
     std::printf("  \"primary_ray\": %ld,\n  \"primary_ray_cross\": %ld,\n", primary_dir_ops + mono_o + mono_d + mono_od + cone_axis_dot, primary_dir_ops + mono_o_x + mono_d_x + mono_od_x + cone_axis_dot);
     std::printf("  \"shadow_ray_considered_directional\": %ld,\n  \"shadow_ray_considered_point\": %ld,\n", backface_dot, point_backface);
     std::printf("  \"shadow_ray_traced_directional\": %ld,\n  \"shadow_ray_traced_directional_cross\": %ld,\n", mono_od + 1, mono_od_x + 1);
     std::printf("  \"shadow_ray_traced_point\": %ld,\n  \"shadow_ray_traced_point_cross\": %ld,\n", 3 + mono_d + mono_od + 1, 3 + mono_d_x + mono_od_x + 1);
-    std::printf("  \"hit\": %ld,\n  \"hit_cross\": %ld,\n", hit_point + normal_ops + 4 * (bias_ops + mono_o), hit_point + normal_ops + 4 * (bias_ops + mono_o_x));
+    std::printf("  \"hit\": %ld,\n  \"hit_cross\": %ld,\n  \"hit_spheres_only\": %ld,\n", hit_point + normal_ops + 4 * (bias_ops + mono_o), hit_point + normal_ops + 4 * (bias_ops + mono_o_x),
+                hit_point + sphere_normal_ops + 4 * (bias_ops + mono_o));
     std::printf("  \"shade_directional\": %ld,\n  \"shade_point\": %ld,\n", shade_directional, shade_point);
     std::printf("  \"reflect_ray\": %ld,\n  \"reflect_ray_cross\": %ld,\n", reflect_ops + bias_ops + mono_o + mono_d + mono_od, reflect_ops + bias_ops + mono_o_x + mono_d_x + mono_od_x);
     std::printf("  \"chunk_ball\": %ld\n },\n", ball_ops);
+    // divisions and square roots inside the units above (each counted as ONE operation there).  The compiler expands an FP64 division
+    // into ~12 and a square root into ~14 FP64 instruction-flops (v_rcp / v_rsq seed + Newton steps in FMAs); bench.py uses these
+    // counts to put the table on the footing of the hardware's instruction counters when it cross-checks the two.
+    std::printf(" \"div_sqrt\": {\n");
+    std::printf("  \"solve_unitsq\": [%.1f, %.1f], \"solve_quadric\": [%.1f, %.1f], \"cubic_quadratic\": [%.1f, %.1f],\n", solve_ds.div, solve_ds.sqrt, solve_ds.div, solve_ds.sqrt, solve_ds.div, solve_ds.sqrt);
+    std::printf("  \"solve_linear\": [%.1f, %.1f], \"cubic_linear\": [%.1f, %.1f], \"cubic_cardano\": [%.1f, %.1f], \"cubic_trig\": [%.1f, %.1f],\n", lin_ds.div, lin_ds.sqrt, lin_ds.div, lin_ds.sqrt,
+                cardano_ds.div, cardano_ds.sqrt, trig_ds.div, trig_ds.sqrt);
+    std::printf("  \"cull_primary\": [%.1f, %.1f], \"primary_ray\": [%.1f, %.1f], \"primary_ray_cross\": [%.1f, %.1f],\n", cone_ds.div, cone_ds.sqrt, pdir_ds.div, pdir_ds.sqrt, pdir_ds.div, pdir_ds.sqrt);
+    std::printf("  \"hit\": [%.1f, %.1f], \"hit_cross\": [%.1f, %.1f], \"hit_spheres_only\": [%.1f, %.1f], \"shade_point\": [%.1f, %.1f], \"chunk_ball\": [0.0, 1.0]\n },\n", normal_ds.div, normal_ds.sqrt,
+                normal_ds.div, normal_ds.sqrt, normal_ds.div, normal_ds.sqrt, shade_pt_ds.div, shade_pt_ds.sqrt);
     std::printf(" \"special_functions\": {\"cubic_cardano\": %ld, \"cubic_trig\": %ld},\n", special_cardano, special_trig);
     std::printf(" \"reference_dense\": {\"expansion\": 286, \"linear\": 1, \"quadratic_miss\": 4, \"quadratic_hit\": 8, \"cardano\": 26, \"trig\": 39, \"normal_vector\": 79,\n"
                 "  \"source\": \"SURVEY.md 8(d): the reference's as-written count per intersect_ray call (include/surface_impl.h:21-155)\"}\n}\n");

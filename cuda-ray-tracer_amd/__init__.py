@@ -15,12 +15,12 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355rt.so")
+LIB_PATH = os.environ.get("MI355RT_LIB") or os.path.join(_HERE, "libmi355rt.so")   # MI355RT_LIB: another build of the same ABI, for A/B measurements
 UPDATE_LIB_PATH = os.path.join(_HERE, "libmi355rt_update.so")
 MULTI_LIB_PATH = os.path.join(_HERE, "libmi355rt_multi.so")   # several GPUs behind one call; the only library that links RCCL
 
 RT_NCOEF = 20
-RT_FLAG_STRICT, RT_FLAG_FAST, RT_FLAG_COUNT, RT_FLAG_SIMPLE, RT_FLAG_NOCULL, RT_FLAG_STATIC_ORDER, RT_FLAG_NOSCAN = 0, 1, 2, 4, 8, 16, 32
+RT_FLAG_STRICT, RT_FLAG_FAST, RT_FLAG_COUNT, RT_FLAG_SIMPLE, RT_FLAG_NOCULL, RT_FLAG_STATIC_ORDER, RT_FLAG_NOSCAN, RT_FLAG_PLAIN_ORDER = 0, 1, 2, 4, 8, 16, 32, 64
 RT_FMT_RGBA32F, RT_FMT_RGBA8 = 0, 1
 RT_ERR_NO_DEVICE = -4
 

@@ -378,6 +378,7 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
     fa.tiles_x = (sd->width + RT_TILE - 1) / RT_TILE;
     fa.n_tiles = fa.tiles_x * ((ctx->local_rows + RT_TILE - 1) / RT_TILE);
     fa.rgba8 = cfg.format == RT_FMT_RGBA8 ? 1u : 0u;
+    fa.ord_plain = (cfg.flags & RT_FLAG_PLAIN_ORDER) ? 1u : 0u;
     fa.has_mirror = 0;
     for (uint32_t i = 0; i < sd->n_objects; i++)
         if ((double) sd->reflection[i] > 1e-7) fa.has_mirror = 1; // EPS of the reflection loop, src/update-cpu.cpp:101
@@ -531,7 +532,7 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
             hip_ok(hipMemcpy(ctx->d_camy, cy.data(), sizeof(double) * sd->height, hipMemcpyHostToDevice), "hipMemcpy(camy)");
         if (rc == RT_OK && !(cfg.flags & (RT_FLAG_SIMPLE | RT_FLAG_STATIC_ORDER)) && fa.n_tiles > 0 && fa.n_tiles <= RT_ORD_MAX_TILES) {
             // launch-order feedback: three generations, all empty (first frame = index order)
-            fa.ord_stride = (RT_ORD_HDR + 5u * fa.n_tiles + 15u) & ~15u;
+            fa.ord_stride = (RT_ORD_HDR + 17u * fa.n_tiles + 15u) & ~15u;
             const size_t bytes = sizeof(uint32_t) * 3u * fa.ord_stride;
             hip_ok(hipMalloc((void **) &fa.order_state, bytes), "hipMalloc(order)") && hip_ok(hipMemset(fa.order_state, 0, bytes), "hipMemset(order)");
             // the kernel reports the number of listed tiles through one host-mapped word; without it (allocation
@@ -640,7 +641,11 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
             const uint64_t want = (uint64_t) seen + seen / 4u + 64u;
             if (want < cap) cap = (uint32_t) want;
             const uint64_t with_hits = (uint64_t) census * 16u;
-            if (ctx->ord_on ? with_hits * 4u >= fa.n_tiles : with_hits * 5u < fa.n_tiles) ctx->ord_on = !ctx->ord_on;
+            // ... and while so many tiles have hits that the launch is more than a dozen rounds of workgroups deep anyway (8K: 20 000 tiles, 16
+            // rounds): there the order buys nothing any more (measured: 477 us either way) and the lists only cost their upkeep
+            const bool too_many = ctx->ord_on ? with_hits >= 16384u : with_hits >= 12288u;
+            const bool too_dense = ctx->ord_on ? with_hits * 4u >= fa.n_tiles : with_hits * 5u >= fa.n_tiles;
+            ctx->ord_on = !(too_many || too_dense);
         }
         fa.ord_cap = cap;
         fa.ord_on = ctx->ord_on ? 1u : 0u;

@@ -120,8 +120,8 @@ struct FrameArgs {
     // round-0 hits take a slot each, background tiles are not stored.
     uint32_t sparse, sparse_cap;
     // Launch-order feedback (wavefront kernel): three generations, ord_stride words apart, of
-    //   { count[4] (classes 4,3,2,1), census, pad[11], word[n_tiles], list[4][n_tiles] }     (uint32)
-    // word[t] = (position in its class list << 3) | class, written only by tiles with hits (a stale word is harmless: the
+    //   { count[16] (cost classes, 0 = the costliest), census, largest cost, pad[14], word[n_tiles], list[16][n_tiles] }     (uint32)
+    // word[t] = (position in its class list << 5) | (class + 1), written only by tiles with hits (a stale word is harmless: the
     // reader checks that the list entry it points at names tile t).  Frame k reads what frame k-1 wrote, writes its
     // own generation and clears the counters frame k+1 will append to.  NULL = tiles run in index order.
     uint32_t *order_state;
@@ -129,6 +129,7 @@ struct FrameArgs {
     uint32_t ord_stride, ord_read, ord_write, ord_zero;
     uint32_t ord_cap;     // list slots in this launch (the grid is n_scan + ord_cap + n_tiles workgroups)
     uint32_t ord_on;      // 0: index order this frame, census only
+    uint32_t ord_plain;   // 1: RT_FLAG_PLAIN_ORDER (A/B): list slot q renders list entry q instead of the balanced (snake) assignment
     // Tile words (all_cullable scenes; rt_wavefront.hip, "tile words"): the first n_scan workgroups of the grid classify
     // RT_SCAN_TILES tiles each and publish tile_state[t] = (frame_tag << 3) | EMPTY / NONEMPTY / COVERED, paint workgroups paint the
     // EMPTY ones, and the workgroup that gets tile t in index order leaves at once when the word says EMPTY.
@@ -140,7 +141,7 @@ struct FrameArgs {
 #define RT_TILE 16        // a workgroup renders a 16 x 16 pixel tile
 #define RT_SCAN_TILES 64  // tiles classified by one classifying workgroup: sixteen per wave
 #define RT_PAINT_TILES 16 // tiles one paint workgroup is responsible for: four per wave
-#define RT_ORD_HDR 16      // words before word[] in one generation of FrameArgs::order_state
+#define RT_ORD_HDR 32      // words before word[] in one generation of FrameArgs::order_state
 #define RT_ORD_MAX_TILES 262144u // 8K frames (129 600 tiles) included: the order still pays there (measured), the state is 20 B per tile and generation
 
 #endif

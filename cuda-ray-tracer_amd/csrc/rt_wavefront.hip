@@ -78,7 +78,8 @@ __device__ __forceinline__ uint32_t tile_py(uint32_t tid) { return (tid >> 7) * 
 // one private 16-word row per wave (pointer in counters[31]) -- no atomics, which would distort the timings.  Words 0-11: cycles
 // per phase; 12 / 13: constant-rate clock (100 MHz) at the wave's start / end, for tools/timeline.py
 #define RT_STAMP_FLUSH(c, lane) do { if ((lane) == 0) { unsigned long long *row_ = reinterpret_cast<unsigned long long *>((c)[31]) + \
-    ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; for (int i_ = 0; i_ < 12; i_++) row_[i_] = ph_[i_]; row_[12] = w0_; row_[13] = wall_clock64(); row_[14] = info_; } } while (0)
+    ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; for (int i_ = 0; i_ < 12; i_++) row_[i_] = ph_[i_]; row_[12] = w0_; row_[13] = wall_clock64(); row_[14] = info_; \
+    row_[15] = ((unsigned long long) __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned) __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } } while (0)
 #define RT_STAMP_INFO(x) do { info_ = (x); } while (0)
 #else
 #define RT_STAMP_DECL
@@ -245,6 +246,64 @@ __device__ __forceinline__ unsigned long long primary_cone_mask(const UsEntry *u
     return __ballot(rel);
 }
 
+// ---- launch order: which list entry does list slot q render? -------------------------------------------------------------------
+// One generation of FrameArgs::order_state (uint32 words):
+//   [0 .. 15]  number of tiles listed in cost class k (k = 0: the costliest)      [16] census      [17] largest tile cost seen
+//   [RT_ORD_HDR + t]                        word of tile t: (position in its class list << 5) | (k + 1); 0 / stale = look again
+//   [RT_ORD_HDR + (1 + k) * n_tiles + i]    i-th tile of class k
+// The concatenation class 0, class 1, ... is the tiles in (roughly) descending cost; `rank` indexes it.
+constexpr uint32_t ORD_CLASSES = 16;
+struct OrdHeader {
+    uint32_t cnt[ORD_CLASSES];
+    uint32_t census, cost_max, n_listed;
+};
+template <typename Words>
+__device__ __forceinline__ OrdHeader ord_header(Words rd)
+{
+    OrdHeader h;
+    h.n_listed = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < ORD_CLASSES; k++) {
+        h.cnt[k] = rd[k];
+        h.n_listed += h.cnt[k];
+    }
+    h.census = rd[16];
+    h.cost_max = rd[17];
+    return h;
+}
+// class and index of list entry `rank` (rank < h.n_listed)
+__device__ __forceinline__ void ord_locate(const OrdHeader &h, uint32_t rank, uint32_t &k, uint32_t &idx)
+{
+    k = 0;
+    idx = rank;
+#pragma unroll
+    for (uint32_t c = 0; c + 1 < ORD_CLASSES; c++) {
+        const bool next = (k == c) && idx >= h.cnt[c];
+        idx -= next ? h.cnt[c] : 0u;
+        k += next ? 1u : 0u;
+    }
+}
+// rank of the first entry of class k
+__device__ __forceinline__ uint32_t ord_first(const OrdHeader &h, uint32_t k)
+{
+    uint32_t f = 0;
+#pragma unroll
+    for (uint32_t c = 0; c + 1 < ORD_CLASSES; c++) f += c < k ? h.cnt[c] : 0u;
+    return f;
+}
+// Which entry list slot q gets.  At the start of a launch the dispatcher deals the workgroups out round robin -- workgroup b and
+// b + 256 land on the same CU (measured: tools/timeline.py) -- and with one workgroup per slot nothing is re-balanced later, so a
+// CU's load is the sum of the entries of its column.  Entries are in descending cost, so the rows alternate direction (a
+// "snake"): the CU that got the costliest tile of one row gets the cheapest of the next.  `first_block` = blockIdx of slot 0.
+__device__ __forceinline__ uint32_t ord_rank_of_slot(uint32_t q, uint32_t n_eff, uint32_t first_block)
+{
+    const uint32_t off = first_block & 255u, row = (q + off) >> 8;
+    if (!(row & 1u)) return q;
+    const uint32_t lo = row * 256u - off;                                   // (row >= 1)
+    const uint32_t hi = (row + 1u) * 256u - off < n_eff ? (row + 1u) * 256u - off : n_eff;
+    return lo + (hi - 1u - q);
+}
+
 // ---- tile words: who deals with an empty tile (all-sphere scenes) -------------------------------------------------------
 // 83 % of config 2's tiles are empty, and a workgroup per empty tile that loads its arguments, reads the launch-order state,
 // lets one wave test the tile, passes a barrier and paints 256 pixels holds a slot for ~2 us: 13 us of a 57 us frame at
@@ -334,16 +393,16 @@ __device__ __forceinline__ void classify_tiles(const FrameArgs &fa, const UsEntr
         uint32_t st = nonempty ? ST_NONEMPTY : ST_EMPTY;
         if (nonempty && ord_rd) { // launch-order lists in use: does a list slot of this launch render the tile?  (the test of the index slots, made here
                                   // once, so that the index slot of a covered tile leaves after one load as well)
-            const uint32_t cn0 = ord_rd[0], cn1 = ord_rd[1], cn2 = ord_rd[2], cn3 = ord_rd[3];
-            const uint32_t e1 = cn0, e2 = e1 + cn1, e3 = e2 + cn2, n_listed = e3 + cn3;
-            const uint32_t n_eff = n_listed < ord_cap ? n_listed : ord_cap;
-            const uint32_t w = ord_rd[RT_ORD_HDR + t]; // (position in its class list << 3) | class: a hint where to look, possibly stale
-            const uint32_t cls = w & 7u, pos = w >> 3;
-            if (cls >= 1u && cls <= 4u && pos < n_tiles) {
-                const uint32_t k = 4u - cls;
-                const uint32_t first = k == 0 ? 0u : (k == 1 ? e1 : (k == 2 ? e2 : e3));
-                const uint32_t count = k == 0 ? cn0 : (k == 1 ? cn1 : (k == 2 ? cn2 : cn3));
-                if (pos < count && first + pos < n_eff && ord_rd[RT_ORD_HDR + (1u + k) * n_tiles + pos] == t) st = ST_COVERED;
+            const OrdHeader oh = ord_header(ord_rd);
+            const uint32_t n_eff = oh.n_listed < ord_cap ? oh.n_listed : ord_cap;
+            const uint32_t w = ord_rd[RT_ORD_HDR + t]; // (position in its class list << 5) | (class + 1): a hint where to look, possibly stale
+            const uint32_t cls = w & 31u, pos = w >> 5;
+            if (cls >= 1u && cls <= ORD_CLASSES && pos < n_tiles) {
+                const uint32_t k = cls - 1u;
+                uint32_t count = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < ORD_CLASSES; c++) count = c == k ? oh.cnt[c] : count;
+                if (pos < count && ord_first(oh, k) + pos < n_eff && ord_rd[RT_ORD_HDR + (1u + k) * n_tiles + pos] == t) st = ST_COVERED;
             }
         }
         uint32_t expect = old;
@@ -666,7 +725,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     const unsigned char *hot_us,      // gscene + fa.off_us: the unit-sphere table
     const uint32_t *hot_ord_rd,       // the launch-order generation this frame reads (fa.order_state + ord_read * ord_stride)
     uint32_t hot_n_us, uint32_t hot_ord_cap, uint32_t hot_n_tiles,
-    uint32_t hot_flags,               // 1: fa.all_cullable   2: launch-order lists in use (fa.order_state && fa.ord_on)   4: paint workgroups
+    uint32_t hot_flags,               // 1: fa.all_cullable   2: launch-order lists in use (fa.order_state && fa.ord_on)   4: paint workgroups   8: list slots take the entries in list order (A/B)
     uint32_t *hot_tile_state,         // fa.tile_state (NULL: no tile words in this launch: every tile's own workgroup decides)
     uint32_t hot_frame_tag, uint32_t hot_n_scan, // fa.frame_tag, fa.n_scan (classifying workgroups)
     const FrameArgs fa, const unsigned char *__restrict__ gscene,
@@ -705,6 +764,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     uint32_t *s_wcount = reinterpret_cast<uint32_t *>(smem + L.misc); // [4] hits found by each wave this round
     uint32_t *s_live = s_wcount + 4;                                  // [4] per-wave "still bouncing" flags
     uint32_t *s_sparse = s_wcount + 8;                                // [1] sparse output: this tile's slot in the message (or none)
+    uint32_t *s_cost = s_wcount + 9;                                  // [1] round 0: work of the shadow phase, for the next frame's launch order
 
     // `wave` through readfirstlane: the compiler cannot see that threadIdx.x >> 6 is the same in every lane of a wave, and would otherwise
     // treat every loop and branch that depends on it (the light loop of phase B, "wave < n_chunks", ...) as divergent
@@ -789,15 +849,15 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     uint32_t tile = slot;
     bool listed = false;  // this tile had hits in the previous frame
     bool listing = false; // this frame appends to the lists
+    uint32_t cost_scale = 0; // largest tile cost of the previous frame: the scale of the cost classes
     bool covered = false; // index-order slot whose tile a list slot renders: leaves before its first side effect
     if (fa.order_state && !fa.ord_on) { // launch-uniform: census only
         ord_wr = fa.order_state + (size_t) fa.ord_write * fa.ord_stride;
         if (slot == 0 && tid == 0) {
             const uint32_t *ord_rd = fa.order_state + (size_t) fa.ord_read * fa.ord_stride;
             uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride;
-            *reinterpret_cast<uint4 *>(z) = make_uint4(0, 0, 0, 0);
-            z[4] = 0;
-            if (fa.ord_host) { fa.ord_host[0] = 0; fa.ord_host[1] = ord_rd[4]; }
+            for (uint32_t k = 0; k < 20; k += 4) *reinterpret_cast<uint4 *>(z + k) = make_uint4(0, 0, 0, 0);
+            if (fa.ord_host) { fa.ord_host[0] = 0; fa.ord_host[1] = ord_rd[16]; }
         }
     }
     if (hot_flags & 2u) { // launch-uniform
@@ -806,44 +866,42 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         typedef const __attribute__((address_space(4))) uint32_t *ConstWords;
         ConstWords ord_rd = (ConstWords) hot_ord_rd;
         ord_wr = fa.order_state + (size_t) fa.ord_write * fa.ord_stride;
-        const uint32_t cn_x = ord_rd[0], cn_y = ord_rd[1], cn_z = ord_rd[2], cn_w = ord_rd[3]; // listed tiles of class 4, 3, 2, 1
-        const uint32_t census = ord_rd[4];                          // tiles with hits in the previous frame, 1 in 16 counted
+        const OrdHeader oh = ord_header(ord_rd); // listed tiles per cost class, census (tiles with hits in the previous frame, 1 in 16 counted), largest cost
         // the per-tile word of an index-order slot is requested with them (for a list slot: tile 0's, unused)
         const uint32_t idx_tile = slot >= hot_ord_cap ? slot - hot_ord_cap : 0u;
-        const uint32_t w = ord_rd[RT_ORD_HDR + idx_tile]; // (position in its class list << 3) | class, 0 = had no hits
+        const uint32_t w = ord_rd[RT_ORD_HDR + idx_tile]; // (position in its class list << 5) | (class + 1), 0 = had no hits
         // ask for the camera / frame part of the kernel arguments here, between issuing the order-state reads and using
         // them: otherwise the compiler sinks those loads below the order decode and a workgroup starts with three
         // dependent round trips (arguments, order state, arguments again)
         asm volatile("" ::"s"(fa.cam[0]), "s"(fa.cam[2]), "s"(fa.cam[5]), "s"(fa.cam[6]), "s"(fa.cam[8]), "s"(fa.cam[10]), "s"(fa.origin[0]),
                      "s"(fa.origin[2]), "s"(fa.aspect), "s"(fa.tan_half_fov), "s"(fa.width), "s"(fa.local_rows), "s"(fa.tiles_x), "s"(fa.n_us),
                      "s"(fa.off_us), "s"(fa.band_rows), "s"(fa.all_cullable), "s"(gscene), "s"(w));
-        listing = census * 64u < hot_n_tiles;                        // the host's switch lags a few frames: same rule here
-        const uint32_t e1 = cn_x, e2 = e1 + cn_y, e3 = e2 + cn_z, n_listed = e3 + cn_w;
-        const uint32_t n_eff = n_listed < hot_ord_cap ? n_listed : hot_ord_cap;
+        listing = oh.census * 64u < hot_n_tiles;                     // the host's switch lags a few frames: same rule here
+        cost_scale = oh.cost_max;
+        const uint32_t n_eff = oh.n_listed < hot_ord_cap ? oh.n_listed : hot_ord_cap;
         if (slot == 0 && tid == 0) {
             uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride; // the generation the NEXT frame appends to
-            *reinterpret_cast<uint4 *>(z) = make_uint4(0, 0, 0, 0);
-            z[4] = 0;
-            if (fa.ord_host) { fa.ord_host[0] = n_listed; fa.ord_host[1] = census; } // host-mapped: sizes / switches later launches
+            for (uint32_t k = 0; k < 20; k += 4) *reinterpret_cast<uint4 *>(z + k) = make_uint4(0, 0, 0, 0);
+            if (fa.ord_host) { fa.ord_host[0] = oh.n_listed; fa.ord_host[1] = oh.census; } // host-mapped: sizes / switches later launches
         }
         if (slot < hot_ord_cap) {
             if (slot >= n_eff) return; // workgroup-uniform
-            const uint32_t b = slot;
-            const uint32_t k = b < e1 ? 0u : (b < e2 ? 1u : (b < e3 ? 2u : 3u));
-            const uint32_t first = k == 0 ? 0u : (k == 1 ? e1 : (k == 2 ? e2 : e3));
-            tile = ord_rd[RT_ORD_HDR + (1u + k) * hot_n_tiles + (b - first)];
+            uint32_t k, idx;
+            ord_locate(oh, (hot_flags & 8u) ? slot : ord_rank_of_slot(slot, n_eff, blockIdx.x - slot), k, idx); // 8: A/B switch, entries in list order
+            tile = ord_rd[RT_ORD_HDR + (1u + k) * hot_n_tiles + idx];
             if (tile >= hot_n_tiles) return; // never true for lists this kernel wrote; keeps a corrupted list harmless
             listed = true;
         } else {
             tile = idx_tile;
             // A tile without hits writes nothing, so its word may be left over from an older frame of this generation:
             // the word is only a hint where to look, and the tile counts as covered iff that list entry really names it.
-            const uint32_t cls = w & 7u, pos = w >> 3;
-            if (tstate == ST_TIMEOUT && cls >= 1u && cls <= 4u && pos < hot_n_tiles) { // (NONEMPTY: its classifier already found it uncovered)
-                const uint32_t k = 4u - cls;
-                const uint32_t first = k == 0 ? 0u : (k == 1 ? e1 : (k == 2 ? e2 : e3));
-                const uint32_t count = k == 0 ? cn_x : (k == 1 ? cn_y : (k == 2 ? cn_z : cn_w));
-                if (pos < count && first + pos < n_eff) covered = ord_rd[RT_ORD_HDR + (1u + k) * hot_n_tiles + pos] == tile;
+            const uint32_t cls = w & 31u, pos = w >> 5;
+            if (tstate == ST_TIMEOUT && cls >= 1u && cls <= ORD_CLASSES && pos < hot_n_tiles) { // (NONEMPTY: its classifier already found it uncovered)
+                const uint32_t k = cls - 1u;
+                uint32_t count = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < ORD_CLASSES; c++) count = c == k ? oh.cnt[c] : count;
+                if (pos < count && ord_first(oh, k) + pos < n_eff) covered = ord_rd[RT_ORD_HDR + (1u + k) * hot_n_tiles + pos] == tile;
             }
         }
     }
@@ -1016,11 +1074,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             if (first && fa.sparse && tid == 0 && n_hits) // sparse output: a tile with hits takes a slot of the message; the slot
                 sp_pos = atomicAdd(reinterpret_cast<uint32_t *>(fb), 1u); // number is published at phase C, used at the final store
             if (first && ord_wr && tid == 0 && n_hits) { // the next frame's launch order: round-0 hits in four cost classes
-                if (((tile * 0x9E3779B1u) >> 28) == 0u) atomicAdd(&ord_wr[4], 1u); // census, also while the ordering is off
-                if (listing) {
-                    ord_cls = 1u + ((n_hits - 1u) >> 6); // 1..64 -> 1, ..., 193..256 -> 4
-                    ord_pos = atomicAdd(&ord_wr[4u - ord_cls], 1u); // only needed at the very end: the round trip costs nothing
-                }
+                if (((tile * 0x9E3779B1u) >> 28) == 0u) atomicAdd(&ord_wr[16], 1u); // census, also while the ordering is off
             }
             if (first) RT_STAMP_INFO(((unsigned long long) tile << 32) | n_hits);
             if (n_hits == 0) break; // workgroup-uniform: nothing left to shade or bounce (all lanes are dead by now)
@@ -1050,6 +1104,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             }
             if (tid < n_hits)
                 for (uint32_t w = 0; w < L.shadow_words; w++) sshadow[tid * L.shadow_words + w] = 0;
+            if (first && tid == 0) s_cost[0] = 0;
             lds_barrier();
 
             // ---------------- phase A': chunk bounding balls ----------------
@@ -1081,6 +1136,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             // Every wave visits every chunk and takes the lights l == (wave - chunk) mod 4 of it, so the per-chunk
             // part of the ray (origin, its monomials) is formed once per wave and the lights of a tile with few
             // hits are still spread over all four waves.
+            // The tile's cost for the next frame's launch order: how long its slowest wave spends in the shadow phase (shader clock / 64).
+            // Crude -- it depends a little on what else ran on the CU -- but free: two s_memtime per wave instead of book-keeping per item.
+            const unsigned long long b_t0 = (first && listing) ? __builtin_amdgcn_s_memtime() : 0ull;
             for (uint32_t c = 0; c < n_chunks; c++) { // wave-uniform
                 const uint32_t h = c * 64 + lane;
                 const bool valid = h < n_hits;
@@ -1149,9 +1207,20 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     }
                 }
             }
+            if (first && listing && lane == 0) atomicMax(&s_cost[0], (uint32_t) ((__builtin_amdgcn_s_memtime() - b_t0) >> 6) + 1u);
             RT_STAMP(6);
             lds_barrier();
             RT_STAMP(7);
+            if (first && listing && tid == 0) {
+                // cost class 0 (the costliest) .. 15, on the scale of the previous frame's largest cost; one device atomic per tile with hits
+                // (plus one for the scale), their results only needed at the very end of the workgroup
+                const uint32_t cost = s_cost[0];
+                const uint32_t q = cost_scale ? (uint32_t) (((unsigned long long) cost * ORD_CLASSES) / ((unsigned long long) cost_scale + 1ull)) : ORD_CLASSES - 1u;
+                ord_cls = ORD_CLASSES - (q < ORD_CLASSES - 1u ? q : ORD_CLASSES - 1u); // class + 1
+                ord_pos = atomicAdd(&ord_wr[ord_cls - 1u], 1u);
+                if (cost > cost_scale - cost_scale / 4u) atomicMax(&ord_wr[17], cost); // (only candidates for the maximum bother the counter; if the
+                                                                                         // scene got so much lighter that nobody qualifies, the scale restarts from 0)
+            }
 
             // ---------------- phase C: shade each hit, lights in order ----------------
             if (first && fa.sparse && tid == 0) s_sparse[0] = sp_pos; // the barrier after this phase publishes it
@@ -1261,8 +1330,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         }
         if (ord_cls && ord_pos < fa.n_tiles) { // thread 0 of a tile with hits, ordering on (the bound can only fail if frames
                                                 // were replayed with stale arguments, e.g. from a captured graph: stay in bounds)
-            ord_wr[RT_ORD_HDR + (5u - ord_cls) * fa.n_tiles + ord_pos] = tile;
-            ord_wr[RT_ORD_HDR + tile] = (ord_pos << 3) | ord_cls;
+            ord_wr[RT_ORD_HDR + ord_cls * fa.n_tiles + ord_pos] = tile; // ord_cls = class + 1
+            ord_wr[RT_ORD_HDR + tile] = (ord_pos << 5) | ord_cls;
         }
         RT_STAMP(10);
     }
@@ -1301,7 +1370,7 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
     const bool ordering = fa->order_state && fa->ord_on;
     const unsigned char *hot_us = gs + fa->off_us;
     const uint32_t *hot_ord_rd = ordering ? fa->order_state + (size_t) fa->ord_read * fa->ord_stride : nullptr;
-    uint32_t hot_flags = (fa->all_cullable ? 1u : 0u) | (ordering ? 2u : 0u) | (n_paint ? 4u : 0u);
+    uint32_t hot_flags = (fa->all_cullable ? 1u : 0u) | (ordering ? 2u : 0u) | (n_paint ? 4u : 0u) | (fa->ord_plain ? 8u : 0u);
 #ifdef RT_WF_DEBUG_EXITS
     if (const char *dbg = getenv("MI355RT_DEBUG_EXIT")) hot_flags |= (uint32_t) atoi(dbg) << 8;
 #endif

@@ -73,6 +73,9 @@ typedef struct rt_scene_desc {
 #define RT_FLAG_NOSCAN 32u    /* wavefront kernel: no scan workgroups (every tile's own workgroup decides whether the tile is
                                  empty and paints it); same results, for A/B runs */
 
+#define RT_FLAG_PLAIN_ORDER 64u /* wavefront kernel: the tiles that had hits start in plain descending-cost order instead of the order that
+                                  balances the CUs' loads (rt_wavefront.hip, ord_rank_of_slot); same results, for A/B runs */
+
 /* rt_config.format -- framebuffer pixel format */
 #define RT_FMT_RGBA32F 0u     /* 4 x float per pixel, alpha 1.0: the un-quantised colours the CPU back end
                                  produces (src/update-cpu.cpp:128-131) plus an alpha lane for 16-byte stores */

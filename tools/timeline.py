@@ -22,6 +22,7 @@ r = pkg.Renderer(sc, device=0, flags=flags)
 for _ in range(4):
     ms = r.update()
 rows = r.stamp_rows()
+row_index = np.nonzero(rows[:, 13] > 0)[0]
 rows = rows[rows[:, 13] > 0]
 t0 = rows[:, 12].min()
 start = (rows[:, 12] - t0).astype(np.float64) / 100.0   # 100 MHz -> us
@@ -65,3 +66,25 @@ print("longest tiles: tile, hits, lifetime us, setup / A / B / C of its slowest 
 for j in order:
     v = wg[keys[j]]
     print(f"  tile {keys[j]:5d} hits {v['hits']:3d} life {life[j]:5.1f}  setup {v['setup']/2400.0:4.1f} A {v['a']/2400.0:4.1f} B {v['b']/2400.0:5.1f} C {v['c']/2400.0:4.1f}")
+# per CU: how much shadow-phase work landed there and when its last tracing wave ended (HW_ID: cu [11:8], sh [12], se [15:13]; XCC_ID [3:0])
+hw = rows[:, 15]
+xcc = (hw >> np.uint64(32)) & np.uint64(0xF)
+hwid = hw & np.uint64(0xFFFFFFFF)
+cu = ((xcc << np.uint64(8)) | (((hwid >> np.uint64(13)) & np.uint64(7)) << np.uint64(5)) | (((hwid >> np.uint64(12)) & np.uint64(1)) << np.uint64(4)) | ((hwid >> np.uint64(8)) & np.uint64(0xF))).astype(np.int64)
+cus = np.unique(cu[traced])
+work = np.array([rows[traced & (cu == c), 6].sum() / 2400.0 for c in cus])      # wave-us of shadow phase
+nw = np.array([int((traced & (cu == c)).sum()) for c in cus])
+last = np.array([end[traced & (cu == c)].max() for c in cus])
+print(f"{len(cus)} CUs ran tracing waves: waves per CU min {nw.min()} median {int(np.median(nw))} max {nw.max()}; shadow-phase wave-us per CU min {work.min():.0f} median {np.median(work):.0f} max {work.max():.0f};"
+      f" last tracing wave ends: min {last.min():.1f} median {np.median(last):.1f} max {last.max():.1f} us; correlation(work, end) {np.corrcoef(work, last)[0, 1]:.2f}")
+# which workgroups (in dispatch order) landed on which CU?
+blocks = row_index // 4
+for c in cus[:6]:
+    b = np.unique(blocks[traced & (cu == c)])
+    print(f"  CU {int(c):5d} (xcc {int(c) >> 8}): tracing workgroups (blockIdx) {b.tolist()}")
+first = {}
+for i in np.argsort(blocks):
+    if traced[i]:
+        first.setdefault(int(blocks[i]), int(cu[i]))
+seq = [first[b] for b in sorted(first)][:48]
+print("  CU of the first 48 tracing workgroups in blockIdx order:", [f"{c >> 8}.{c & 255}" for c in seq])

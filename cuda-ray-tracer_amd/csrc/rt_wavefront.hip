@@ -713,26 +713,103 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
     return blocker;
 }
 
+struct HotArgs { // the preloaded prefix of the kernel arguments, for the offset of what follows
+    const unsigned char *hot_us;
+    const uint32_t *hot_ord_rd;
+    uint32_t hot_n_us, hot_ord_cap, hot_n_tiles, hot_flags;
+    uint32_t *hot_tile_state;
+    uint32_t hot_frame_tag, hot_n_scan;
+};
+struct ColdArgs {
+    FrameArgs fa;
+    const unsigned char *gscene;
+    const DevLight *glight;
+    void *fb;
+    unsigned long long *counters;
+    const double *camx, *camy;
+};
+static_assert(sizeof(HotArgs) == 48 && alignof(ColdArgs) == 8, "kernel argument layout");
+// the cold arguments where they sit in the kernarg segment (constant address space: uniform addresses become scalar loads); the
+// pointer goes through an empty asm so that no load from it can be moved above this point
+__device__ __forceinline__ const ColdArgs &cold_args()
+{
+    typedef const __attribute__((address_space(4))) unsigned char *KernargBytes;
+    KernargBytes p = (KernargBytes) __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const ColdArgs *) (p + sizeof(HotArgs));
+}
+
 // HAS_MIRROR = some object has reflection_ratio > EPS.  Without mirrors every pixel is finished after round 0, the
 // round loop is known to run once and the bounce state (ray direction, blend ratio, depth) is dead during the shadow
 // phase -- which is what lets the mirror-free instantiation fit 128 VGPRs (4 waves per SIMD).
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR>
 __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MIRROR>())) void wavefront_tile_kernel(
-    // The first eight dwords of the kernel arguments are PRELOADED into SGPRs at wave launch (kernarg preload, gfx940+;
-    // the object is built with -amdgpu-kernarg-preload-count=8): with them a workgroup can request its sphere entries
-    // and the launch-order state in its very first instructions, in parallel with the loads of everything else,
-    // instead of one round trip later.  They repeat values of `fa`; rt_launch_wavefront fills both.
+    // The first twelve dwords of the kernel arguments are PRELOADED into SGPRs at wave launch (kernarg preload, gfx940+; the
+    // object is built with -amdgpu-kernarg-preload-count=12): with them a workgroup decides what it is in its very first
+    // instructions -- an index slot reads its tile's word and, nine times out of ten, leaves without ever fetching the rest.
+    // They repeat values of `fa`; rt_launch_wavefront fills both.
     const unsigned char *hot_us,      // gscene + fa.off_us: the unit-sphere table
     const uint32_t *hot_ord_rd,       // the launch-order generation this frame reads (fa.order_state + ord_read * ord_stride)
     uint32_t hot_n_us, uint32_t hot_ord_cap, uint32_t hot_n_tiles,
     uint32_t hot_flags,               // 1: fa.all_cullable   2: launch-order lists in use (fa.order_state && fa.ord_on)   4: paint workgroups   8: list slots take the entries in list order (A/B)
     uint32_t *hot_tile_state,         // fa.tile_state (NULL: no tile words in this launch: every tile's own workgroup decides)
     uint32_t hot_frame_tag, uint32_t hot_n_scan, // fa.frame_tag, fa.n_scan (classifying workgroups)
-    const FrameArgs fa, const unsigned char *__restrict__ gscene,
-                                                              const DevLight *__restrict__ glight, void *__restrict__ fb,
-                                                              unsigned long long *__restrict__ counters,
-                                                              const double *__restrict__ camx, const double *__restrict__ camy)
+    // Everything else.  NEVER referenced by name: the compiler loads every kernel argument it sees used in the entry block, and with
+    // ~150 argument dwords it then spills them to VGPR lanes right there -- five serialised fetch / wait / spill rounds before the
+    // first branch, paid by every one of the 8 160 (1080p) .. 129 600 (8K) index slots.  The body reads them through the kernarg
+    // segment pointer instead (cold_args() below), after the index slots have left.
+    const ColdArgs cold_never_named)
 {
+    // `wave` through readfirstlane: the compiler cannot see that threadIdx.x >> 6 is the same in every lane of a wave, and would otherwise
+    // treat every loop and branch that depends on it (the light loop of phase B, "wave < n_chunks", ...) as divergent
+    const uint32_t tid = threadIdx.x, wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = tid & 63;
+    // ---- roles: [classify][list slots][paint + index slots]; `slot` counts the tracing workgroups (list slots, then index order).
+    // Decided from the preloaded arguments alone.
+    constexpr bool ALL_SPHERES_POSSIBLE = !HAS_GQ && !HAS_CUBIC; // fa.all_cullable needs a scene of spheres only
+    const uint32_t ord_slots = (hot_flags & 2u) ? hot_ord_cap : 0u;
+    uint32_t slot = blockIdx.x;
+    uint32_t tstate = ST_TIMEOUT; // verdict on this workgroup's tile; TIMEOUT = decide here (no tile words, list slots, gave up polling)
+    uint32_t role = 0, paint_block = 0; // 0 trace a tile, 1 classify, 2 paint
+    if (ALL_SPHERES_POSSIBLE && hot_tile_state) { // launch-uniform
+        if (blockIdx.x < hot_n_scan) { // workgroup-uniform
+            role = 1;
+        } else {
+            slot -= hot_n_scan;
+            if (slot >= ord_slots) {
+                // behind the list slots: one paint workgroup in front of every RT_PAINT_TILES index slots (its own sixteen tiles' slots),
+                // so that the painting -- HBM-bound -- runs beside the index slots, which are bound by the dispatch rate
+                const uint32_t q = slot - ord_slots;
+                if (hot_flags & 4u) {
+                    const uint32_t grp = q / (RT_PAINT_TILES + 1u), pos = q - grp * (RT_PAINT_TILES + 1u);
+                    if (pos == 0u) { // workgroup-uniform
+                        role = 2;
+                        paint_block = grp;
+                    }
+                    slot = ord_slots + grp * RT_PAINT_TILES + (pos - 1u);
+                    if (role == 0 && slot - ord_slots >= hot_n_tiles) return; // the last group may be partial
+                }
+                if (role == 0) {
+                    // index slot of tile slot - ord_slots: its word decides, and every wave of the workgroup reads the same decided value
+                    uint32_t *w = hot_tile_state + (slot - ord_slots);
+                    uint32_t v = 0;
+                    if (lane == 0) v = tile_word_wait(w, hot_frame_tag, tile_word_load(w));
+                    tstate = (uint32_t) __builtin_amdgcn_readfirstlane((int) v) & ST_MASK;
+                    // EMPTY: a paint workgroup paints it and nothing else is to do.  (Counting builds count its rays further down;
+                    // slot 0 may have frame duties when the launch-order lists are off.)
+                    if (!COUNT && tstate == ST_EMPTY && slot != 0u) return;
+                    if (tstate == ST_COVERED) return; // a list slot renders (and counts) it; slot 0 is a list slot whenever the lists are in use
+                }
+            }
+        }
+    }
+    // ---- everything below needs the rest of the arguments ----
+    const ColdArgs &cold = cold_args();
+    const FrameArgs &fa = cold.fa;
+    const unsigned char *__restrict__ gscene = cold.gscene;
+    const DevLight *__restrict__ glight = cold.glight;
+    void *__restrict__ fb = cold.fb;
+    unsigned long long *__restrict__ counters = cold.counters;
+    const double *__restrict__ camx = cold.camx, *__restrict__ camy = cold.camy;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool NEED_CROSS = HAS_GQ || HAS_CUBIC;
     const LdsLayout L(fa.stage_bytes, fa.n_lights, HAS_MIRROR, fa.cull ? fa.n_us : 0u);
@@ -766,9 +843,6 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     uint32_t *s_sparse = s_wcount + 8;                                // [1] sparse output: this tile's slot in the message (or none)
     uint32_t *s_cost = s_wcount + 9;                                  // [1] round 0: work of the shadow phase, for the next frame's launch order
 
-    // `wave` through readfirstlane: the compiler cannot see that threadIdx.x >> 6 is the same in every lane of a wave, and would otherwise
-    // treat every loop and branch that depends on it (the light loop of phase B, "wave < n_chunks", ...) as divergent
-    const uint32_t tid = threadIdx.x, wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = tid & 63;
     RT_STAMP_DECL
     // No prologue: 83 % of the tiles of a typical frame contain no hit at all, and for those the whole job is
     // "primary rays miss, store the background".  Round 0 therefore reads the (culled, tiny) part of the tables it
@@ -780,46 +854,19 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     Cnt<COUNT> cnt;
     const F3 bg{fa.bg[0], fa.bg[1], fa.bg[2]};
 
-    // ---- roles: [classify][list slots][paint][index slots]; `slot` counts the tracing workgroups (list slots, then index order) ----
-    constexpr bool ALL_SPHERES_POSSIBLE = !HAS_GQ && !HAS_CUBIC; // fa.all_cullable needs a scene of spheres only
-    const uint32_t ord_slots = (hot_flags & 2u) ? hot_ord_cap : 0u;
-    uint32_t slot = blockIdx.x;
-    uint32_t tstate = ST_TIMEOUT; // verdict on this workgroup's tile; TIMEOUT = decide here (no tile words, list slots, gave up polling)
-    if (ALL_SPHERES_POSSIBLE && hot_tile_state) { // launch-uniform
-        if (blockIdx.x < hot_n_scan) { // workgroup-uniform
-            classify_tiles<COUNT>(fa, reinterpret_cast<const UsEntry *>(hot_us), hot_n_us, hot_tile_state, hot_frame_tag, hot_n_tiles,
-                                  (hot_flags & 2u) ? hot_ord_rd : nullptr, hot_ord_cap, wave, lane, cnt);
-            RT_STAMP(11);
-            RT_STAMP_FLUSH(counters, lane);
-            cnt.flush(counters);
-            return;
-        }
-        slot -= hot_n_scan;
-        if (slot >= ord_slots) {
-            // behind the list slots: one paint workgroup in front of every RT_PAINT_TILES index slots (its own sixteen tiles' slots),
-            // so that the painting -- HBM-bound -- runs beside the index slots, which are bound by the dispatch rate
-            const uint32_t q = slot - ord_slots;
-            if (hot_flags & 4u) {
-                const uint32_t grp = q / (RT_PAINT_TILES + 1u), pos = q - grp * (RT_PAINT_TILES + 1u);
-                if (pos == 0u) { // workgroup-uniform
-                    paint_tiles(fa, hot_tile_state, hot_frame_tag, hot_n_tiles, fb, bg, grp, wave, lane);
-                    RT_STAMP(11);
-                    RT_STAMP_FLUSH(counters, lane);
-                    return;
-                }
-                slot = ord_slots + grp * RT_PAINT_TILES + (pos - 1u);
-                if (slot - ord_slots >= hot_n_tiles) return; // the last group may be partial
-            }
-            // index slot of tile slot - ord_slots: its word decides, and every wave of the workgroup reads the same decided value
-            uint32_t *w = hot_tile_state + (slot - ord_slots);
-            uint32_t v = 0;
-            if (lane == 0) v = tile_word_wait(w, hot_frame_tag, tile_word_load(w));
-            tstate = (uint32_t) __builtin_amdgcn_readfirstlane((int) v) & ST_MASK;
-            // EMPTY: a paint workgroup paints it and nothing else is to do.  (Counting builds count its rays further down;
-            // slot 0 may have frame duties when the launch-order lists are off.)
-            if (!COUNT && tstate == ST_EMPTY && slot != 0u) return;
-            if (tstate == ST_COVERED) return; // a list slot renders (and counts) it; slot 0 is a list slot whenever the lists are in use
-        }
+    if (ALL_SPHERES_POSSIBLE && role == 1) { // workgroup-uniform
+        classify_tiles<COUNT>(fa, reinterpret_cast<const UsEntry *>(hot_us), hot_n_us, hot_tile_state, hot_frame_tag, hot_n_tiles,
+                              (hot_flags & 2u) ? hot_ord_rd : nullptr, hot_ord_cap, wave, lane, cnt);
+        RT_STAMP(11);
+        RT_STAMP_FLUSH(counters, lane);
+        cnt.flush(counters);
+        return;
+    }
+    if (ALL_SPHERES_POSSIBLE && role == 2) { // workgroup-uniform
+        paint_tiles(fa, hot_tile_state, hot_frame_tag, hot_n_tiles, fb, bg, paint_block, wave, lane);
+        RT_STAMP(11);
+        RT_STAMP_FLUSH(counters, lane);
+        return;
     }
 #ifdef RT_WF_DEBUG_EXITS
     if ((hot_flags & 0x100u) && slot >= ord_slots) return; // timing experiment: index slots leave at once
@@ -1374,7 +1421,8 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
 #ifdef RT_WF_DEBUG_EXITS
     if (const char *dbg = getenv("MI355RT_DEBUG_EXIT")) hot_flags |= (uint32_t) atoi(dbg) << 8;
 #endif
-#define RT_LAUNCH(C, M, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q, M>), grid, block, lds, stream, hot_us, hot_ord_rd, fa->n_us, fa->ord_cap, fa->n_tiles, hot_flags, n_scan ? fa->tile_state : nullptr, fa->frame_tag, n_scan, *fa, gs, glight, fb, counters, camx, camy)
+    const ColdArgs cold{*fa, gs, glight, fb, counters, camx, camy};
+#define RT_LAUNCH(C, M, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q, M>), grid, block, lds, stream, hot_us, hot_ord_rd, fa->n_us, fa->ord_cap, fa->n_tiles, hot_flags, n_scan ? fa->tile_state : nullptr, fa->frame_tag, n_scan, cold)
     switch (sel) {
     case 0: RT_LAUNCH(false, false, false, false); break;
     case 1: RT_LAUNCH(false, false, false, true); break;

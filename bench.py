@@ -35,6 +35,7 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 FP64 lanes/clk x
 HBM_PEAK_GBS = 8000.0
 DIV_FLOPS_IN_ISA, SQRT_FLOPS_IN_ISA = 12.0, 14.0   # FP64 instruction-flops of hipcc's expansion of one division / square root (see roofline.table_in_pmc_terms)
 PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.txt")
+KERNEL_STATS = "profiles/r02_final_kernel_stats.csv"
 KERNEL_SOURCES = ["cuda-ray-tracer_amd/csrc/rt_wavefront.hip", "cuda-ray-tracer_amd/csrc/rt_math.hpp",
                   "cuda-ray-tracer_amd/csrc/rt_scene_dev.h", "cuda-ray-tracer_amd/csrc/rt_wavefront_math.hpp"]
 
@@ -177,6 +178,22 @@ def kernel_source_digest():
         if os.path.exists(p):
             h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
+
+
+def rocprof_kernel_avg_ms(args, world):
+    """Average duration of the product kernel in the committed rocprofv3 --kernel-trace --stats summary of this command (same
+    workload only); None when the file is missing.  Reported next to this run's own HIP-event figure, never instead of it."""
+    if world != 1 or args.workload != "config2" or args.kernel != "wavefront" or args.mode != "strict" or args.format != "rgba32f" or args.camera != "static":
+        return None
+    try:
+        import csv
+        with open(os.path.join(ROOT, KERNEL_STATS)) as f:
+            for row in csv.DictReader(f):
+                if "wavefront_tile_kernel<false" in row["Name"]:
+                    return float(row["AverageNs"]) * 1e-6
+    except Exception:
+        pass
+    return None
 
 
 def pmc_profile(args, world):
@@ -607,6 +624,12 @@ def run_rank(args, world):
                 "reference_dense_flops_per_frame": dense_frame, "reference_equivalent_tflops": dense_frame / step_s / 1e12,
                 "time_vs_dense_algorithm_at_100pct_fp64_peak": (dense_frame / (FP64_VECTOR_PEAK_TFLOPS * 1e12 * world)) / step_s,
                 "hbm_write_gbs": fb_bytes / (kernel_ms * 1e-3) / 1e9, "hbm_frac": fb_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        rp = rocprof_kernel_avg_ms(args, world)
+        if rp is not None:
+            roof["kernel_ms_what"] = ("time per launch of launches issued back to back (kernel + the ~2.5-3 us the command processor needs between two dependent launches, "
+                                      "profiles/r02_launch_overheads.txt): the conservative denominator")
+            roof["rocprof_kernel_avg_ms"] = rp
+            roof["rocprof_kernel_avg_source"] = f"{KERNEL_STATS} (rocprofv3 --kernel-trace --stats of this command, committed; begin-to-end of the kernel alone)"
         if pmc and "flops" in pmc:
             roof["pmc_flops_per_launch"] = pmc["flops"]
             roof["pmc_flops_formula"] = "(SQ_INSTS_VALU_ADD_F64 + SQ_INSTS_VALU_MUL_F64 + 2 x SQ_INSTS_VALU_FMA_F64) x 64 x active-lane fraction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 64)"

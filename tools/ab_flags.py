@@ -16,6 +16,9 @@ pkg = graft.load_package()
 variants = [a.split("=") for a in sys.argv[1:] if "=" in a] or [["scan", "0"], ["noscan", str(pkg.RT_FLAG_NOSCAN)]]
 variants = [(n, int(f)) for n, f in variants]
 sizes = [(1920, 1080), (3840, 2160), (7680, 4320)]
+SCENE = os.environ.get("AB_SCENE", "20spheres")   # AB_SCENE=reflection_test AB_SIZES=1920x1080 AB_REFL=4 for the other configs
+if os.environ.get("AB_SIZES"):
+    sizes = [tuple(int(v) for v in t.split("x")) for t in os.environ["AB_SIZES"].split(",")]
 away = pkg.camera_matrix((0.0, 0.0, 0.0), -90.0, 0.0)
 poses = [("start", pkg.IDENTITY), ("orbit5", None), ("orbit16", None), ("empty", away)]
 
@@ -32,7 +35,9 @@ poses[1] = ("orbit5", orbit(5))
 poses[2] = ("orbit16", orbit(16))
 stream = torch.cuda.current_stream()
 for W, H in sizes:
-    sc = pkg.Scene.load_from_file(os.path.join(ROOT, "scenes", "20spheres.yml")).set_size(W, H)
+    sc = pkg.Scene.load_from_file(os.path.join(ROOT, "scenes", SCENE + ".yml")).set_size(W, H)
+    if os.environ.get("AB_REFL"):
+        sc.set_max_reflections(int(os.environ["AB_REFL"]))
     fb = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
     rens = [(n, pkg.Renderer(sc, device=0, flags=f)) for n, f in variants]
     reps = 100 if W <= 1920 else (40 if W <= 3840 else 15)

@@ -577,11 +577,17 @@ __device__ __forceinline__ unsigned long long relevant_mask_directional(const Cu
     return __ballot(lane < end && crec_relevant(crec[lane], sdir, inv_uu, len_u));
 }
 
+// Survivors of the ball test from which the box test (rt_wavefront_math.hpp) is run as well.  A chunk whose hits lie on a near and a
+// far object has a long thin box and a fat ball: every sphere near the axis survives the ball (12.7 per item in the slowest tile of
+// orbit pose 6, against 1.2 on average), each costing 27 instructions per wave to find that no lane needs it.  Same-box A/B
+// (1080p, us): threshold 3: start 46.0 -> 46.9, orbit pose 6 67.2 -> 54.4, pose 19 58.4 -> 61.3;  6: 46.2, 54.5, 59.5;  9: no gain.
+constexpr int BOX_STAGE_MIN = 6;
+constexpr uint32_t BOX_EVAL_UNITS = 3; // a box-stage evaluation in units of a directional decision, for the work counters (tools/count_flops.cpp checks the ratio) // survivors of the ball test from which the box test is worth its ~30 instructions
 constexpr uint32_t CREC_MAX = 64; // culling records cover the first group of 64 spheres; further groups take relevant_mask
 
 // LDS carve-up (dynamic shared memory), shared by kernel and launcher.
 struct LdsLayout {
-    uint32_t scene, light, hp, hn, hdir, park, hidx, hpix, color, shadow, ball, crec, n_crec, misc, total, shadow_words;
+    uint32_t scene, light, hp, hn, hdir, park, hidx, hpix, color, shadow, ball, box, crec, n_crec, misc, total, shadow_words;
     __host__ __device__ LdsLayout(uint32_t scene_bytes, uint32_t n_lights, bool has_mirror, uint32_t n_cull_spheres)
     {
         n_crec = n_cull_spheres < CREC_MAX ? n_cull_spheres : CREC_MAX; // culling records per chunk (0: culling is off)
@@ -599,6 +605,7 @@ struct LdsLayout {
         color = off; off = align16(off + 3 * WG * 4);
         shadow = off; off = align16(off + WG * shadow_words * 4);
         ball = off; off = align16(off + 4 * (uint32_t) sizeof(Ball));
+        box = off; off = align16(off + 4 * (uint32_t) sizeof(BoxH));
         crec = off; off = align16(off + 4 * n_crec * (uint32_t) sizeof(CullRec));
         misc = off; off = align16(off + 48);
         total = off;
@@ -611,7 +618,7 @@ constexpr int NO_BLOCKER = 0x7fffffff;
 // object index.  `blocker` keeps the lowest blocking index seen; without COUNT any blocker ends the search.
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool SPHERICAL> // SPHERICAL: the light's kind -- one copy of the loop per kind, each without the other's code
 __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj,
-                                              const Mono &sm, double max_t, bool valid, bool prod, const Ball *ballp, const CullRec *crec, const DevLight &lt,
+                                              const Mono &sm, double max_t, bool valid, bool prod, const Ball *ballp, const BoxH *boxp, const CullRec *crec, const DevLight &lt,
                                               uint32_t lane, Cnt<COUNT> &cnt)
 {
     // valid: lanes whose ray is tested.  prod: lanes the product build tests (== valid there); a counting build tests more lanes --
@@ -625,7 +632,13 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
         unsigned long long cand = 0;
         if (fa.cull) {
             unsigned long long it;
-            if (!SPHERICAL && base == 0) it = relevant_mask_directional(crec, end, sm.d, lt.inv_uu, lt.len_u, lane); // sm.d is this light's FP32-rounded direction
+            if (!SPHERICAL && base == 0) {
+                it = relevant_mask_directional(crec, end, sm.d, lt.inv_uu, lt.len_u, lane); // sm.d is this light's FP32-rounded direction
+                if (__popcll(it) >= BOX_STAGE_MIN) { // wave-uniform: many got through the ball -- look again with the box
+                    it &= __ballot(lane < end && crec_in_box_shadow(crec[lane], *boxp, sm.d));
+                    if (lane == 0 && prod_any) cnt.cull(C_SHADOW_DIR, BOX_EVAL_UNITS * (end - base)); // 30 counted operations: three directional decisions
+                }
+            }
             else it = relevant_mask<SPHERICAL>(S.us, base, end, *ballp, lt, lane); // (the ball is read from LDS here, not kept)
             if (lane == 0 && prod_any) cnt.cull(SPHERICAL ? C_SHADOW_SPH : C_SHADOW_DIR, end - base);
             if (prod) cnt.exec(K_US, (unsigned long long) __popcll(it));
@@ -837,6 +850,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     float *spark = reinterpret_cast<float *>(smem + L.park);      // [5][WG] mirrors: running colour, blend ratio, depth of the pixel
     uint32_t *sshadow = reinterpret_cast<uint32_t *>(smem + L.shadow); // [WG][shadow_words] bit l: light l is blocked
     Ball *sball = reinterpret_cast<Ball *>(smem + L.ball);
+    BoxH *sbox = reinterpret_cast<BoxH *>(smem + L.box);
     CullRec *screc = reinterpret_cast<CullRec *>(smem + L.crec); // [4 chunks][L.n_crec]
     uint32_t *s_wcount = reinterpret_cast<uint32_t *>(smem + L.misc); // [4] hits found by each wave this round
     uint32_t *s_live = s_wcount + 4;                                  // [4] per-wave "still bouncing" flags
@@ -1171,7 +1185,10 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 b.cz = 0.5 * ((double) loz + (double) hiz);
                 // half diagonal of the box (rounded up) + the 1e-2 shadow bias of the ray origins
                 b.R = 0.5 * sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-9) + 1.01e-2;
-                if (lane == 0) sball[wave] = b;
+                if (lane == 0) {
+                    sball[wave] = b;
+                    sbox[wave] = BoxH{0.5 * dx * (1.0 + 1e-9) + 1.01e-2, 0.5 * dy * (1.0 + 1e-9) + 1.01e-2, 0.5 * dz * (1.0 + 1e-9) + 1.01e-2, 0.0};
+                }
                 // the light-independent half of the shadow-phase culling, lane = sphere (first group of 64)
                 if (lane < L.n_crec) screc[wave * L.n_crec + lane] = cull_record(S.us[lane], b);
                 if (lane == 0) cnt.cull(C_RECORDS, L.n_crec);
@@ -1245,8 +1262,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     mono_set_od<NEED_CROSS>(sm);
                     if (wanted) cnt.traced();
                     const int blocker = lt_spherical
-                        ? shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, true>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, screc + c * L.n_crec, lt, lane, cnt)
-                        : shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, false>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, screc + c * L.n_crec, lt, lane, cnt);
+                        ? shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, true>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, sbox + c, screc + c * L.n_crec, lt, lane, cnt)
+                        : shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, false>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, sbox + c, screc + c * L.n_crec, lt, lane, cnt);
                     if (valid) {
                         // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
                         cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);

@@ -280,8 +280,12 @@ __device__ __forceinline__ bool sphere_relevant(const UsEntry &e, const Ball &ba
 // operations in the same order as relevant_mask, hence the same decisions.  Spheres that are never culled carry lim = +inf
 // (NaN radii give NaN: every comparison below is then false, i.e. "test it").
 struct alignas(16) CullRec {
-    double wx, wy, wz, ww, lim, pad;
+    double wx, wy, wz, ww, lim, limr; // limr = lim without the ball's radius: the sphere's own reach, for the box test below
 };                            // 48 B: three 16-byte LDS reads, conflict-free at this stride
+// Half extents of the chunk's bounding box (same centre as its ball), the 1e-2 shadow bias of the ray origins included.
+struct alignas(16) BoxH {
+    double hx, hy, hz, pad;
+};
 
 __device__ __forceinline__ CullRec cull_record(const UsEntry &e, const Ball &ball)
 {
@@ -292,9 +296,10 @@ __device__ __forceinline__ CullRec cull_record(const UsEntry &e, const Ball &bal
     c.ww = c.wx * c.wx + c.wy * c.wy + c.wz * c.wz;
     const double w1 = fabs(c.wx) + fabs(c.wy) + fabs(c.wz);
     const double s2 = ccx * ccx + ccy * ccy + ccz * ccz + ball.cx * ball.cx + ball.cy * ball.cy + ball.cz * ball.cz;
-    c.lim = r + ball.R + 1e-6 * (w1 + r + ball.R + 1.0) + 1e-12 * (s2 + 1.0) * e.inv_r;
-    if (!(r < INFINITY)) c.lim = r; // +inf or NaN: always tested
-    c.pad = 0.0;
+    const double margin = 1e-6 * (w1 + r + ball.R + 1.0) + 1e-12 * (s2 + 1.0) * e.inv_r;
+    c.lim = r + ball.R + margin;
+    c.limr = r + margin;
+    if (!(r < INFINITY)) c.lim = c.limr = r; // +inf or NaN: always tested
     return c;
 }
 
@@ -303,6 +308,23 @@ __device__ __forceinline__ bool crec_relevant(const CullRec &c, const D3 &sdir, 
     const double along = c.wx * sdir.x + c.wy * sdir.y + c.wz * sdir.z;
     const double perp2 = c.ww - along * along * inv_uu;
     return !(perp2 > c.lim * c.lim) && !(along < -c.lim * len_u);
+}
+
+// Second stage for a directional light, used when the ball lets many spheres through (a chunk whose hits lie on a near and a far
+// object has a long thin box and a fat ball).  All shadow rays of the chunk start inside the box and run along sdir, so in the plane
+// perpendicular to sdir they lie inside the box's shadow, a hexagon whose edge normals are sdir x e_k; a sphere can only be met if
+// its centre's projection is within its reach of that hexagon, hence within reach of it along each of the three normals:
+//     |w . (sdir x e_k)|  <=  sum_j h_j |e_j . (sdir x e_k)|  +  reach * |sdir x e_k|,        w = centre - box centre.
+// |sdir x e_k| is bounded by the 1-norm of its two components (no square root; the bound only has to be conservative).
+// reach = limr carries the same margins as the ball test (1e-6 of the distances involved), which dwarf the rounding of the
+// two-term products here.  NaN / inf reach: every comparison is false, the sphere stays.
+__device__ __forceinline__ bool crec_in_box_shadow(const CullRec &c, const BoxH &h, const D3 &sdir)
+{
+    const double ax = fabs(sdir.x), ay = fabs(sdir.y), az = fabs(sdir.z);
+    const double px = c.wy * sdir.z - c.wz * sdir.y, bx = (h.hy * az + h.hz * ay) + c.limr * (ay + az);
+    const double py = c.wz * sdir.x - c.wx * sdir.z, by = (h.hz * ax + h.hx * az) + c.limr * (ax + az);
+    const double pz = c.wx * sdir.y - c.wy * sdir.x, bz = (h.hx * ay + h.hy * ax) + c.limr * (ax + ay);
+    return !(fabs(px) > bx * (1.0 + 1e-9)) && !(fabs(py) > by * (1.0 + 1e-9)) && !(fabs(pz) > bz * (1.0 + 1e-9));
 }
 
 __device__ __forceinline__ void blend(F3 &res, float ratio, const F3 &c)

@@ -372,6 +372,51 @@ def test_fly_through_sequence(pkg, oracle):
     r.cleanup_update()
 
 
+def _orbit_pose(pkg, i, n=24):
+    a = 2.0 * np.pi * i / n
+    pos = (5.0 + 14.0 * np.sin(a), 2.0 + 2.0 * np.sin(2 * a), 15.0 - 14.0 * np.cos(a))
+    return pkg.camera_matrix(pos, float(np.degrees(np.arctan2(15.0 - pos[2], 5.0 - pos[0]))), float(-np.degrees(np.arctan2(pos[1] - 2.0, 14.0))))
+
+
+@pytest.mark.parametrize("pose", [3, 5, 6, 19])
+def test_box_stage_culling_on_orbit_poses(pkg, oracle, pose):
+    """Views along the rows of 20spheres.yml: tiles whose 64-hit chunks span a near and a far sphere (long thin bounding box, fat
+    bounding ball), where the shadow phase's second culling stage (crec_in_box_shadow, rt_wavefront_math.hpp) runs.  The frame
+    must equal the oracle's and the frames of the kernels without that stage."""
+    w, h = 480, 270
+    cam = _orbit_pose(pkg, pose)
+    sc = pkg.Scene.load_from_file(scene_path("20spheres")).set_size(w, h)
+    got = render_desc(pkg, sc, cam)
+    assert np.array_equal(got, render_desc(pkg, sc, cam, flags=pkg.RT_FLAG_NOCULL))
+    assert np.array_equal(got, render_desc(pkg, sc, cam, flags=pkg.RT_FLAG_SIMPLE))
+    assert np.array_equal(got[..., :3], oracle.load_scene(scene_path("20spheres")).with_size(w, h).render(cam=cam, nthreads=8))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_box_stage_culling_on_sphere_rows(pkg, oracle, seed):
+    """Constructed for the box stage: rows of spheres receding from the camera (every tile on a silhouette sees a near and a far
+    one) and directional lights, some of them along the rows, so that many spheres lie near every chunk's axis."""
+    rng = np.random.default_rng(7000 + seed)
+    s = pkg.Scene.new(256, 160, 55.0, 0, (0.05, 0.1, 0.2))
+    for row in range(3):
+        x0, y0 = float(rng.uniform(-3, 3)), float(rng.uniform(-2, 2))
+        for k in range(int(rng.integers(6, 10))):
+            z = 6.0 + 3.2 * k
+            s.add_object(pkg.surface_make("sphere", [x0 + 0.35 * k * (row - 1) + float(rng.normal(0, 0.1)), y0 + 0.25 * k, z], [float(rng.uniform(0.8, 1.4))]),
+                         rng.uniform(0.2, 1, 3), 0.0)
+    for i in range(12):
+        d = np.array([0.1 * (i - 6), -0.3 - 0.05 * i, -1.0 + 0.15 * i]) if i % 2 == 0 else rng.normal(size=3) + np.array([0, -1.0, 0])
+        s.add_light("directional", d, rng.uniform(0.2, 1, 3), float(rng.uniform(0.2, 0.8)))
+    s.add_light("spherical", [0.0, 12.0, 10.0], (1, 1, 1), 300.0)
+    _check_against_oracle(pkg, oracle, s)
+    # the stage really ran: a counting render books its evaluations as directional decisions, three each (rt_wavefront.hip)
+    r = pkg.Renderer(s, device=0, flags=pkg.RT_FLAG_COUNT)
+    r.update()
+    d = r.counters_detail()
+    r.cleanup_update()
+    assert d["cull_by_kind"]["shadow_directional"] > 0
+
+
 def mixed_scene(pkg, seed, w=128, h=96):
     """Random mix of every degree <= 2 class: spheres, ellipsoids / hyperboloids / paraboloids with cross terms, planes;
     directional and point lights; some mirrors."""

@@ -20,7 +20,7 @@ SCENE = os.environ.get("AB_SCENE", "20spheres")   # AB_SCENE=reflection_test AB_
 if os.environ.get("AB_SIZES"):
     sizes = [tuple(int(v) for v in t.split("x")) for t in os.environ["AB_SIZES"].split(",")]
 away = pkg.camera_matrix((0.0, 0.0, 0.0), -90.0, 0.0)
-poses = [("start", pkg.IDENTITY), ("orbit5", None), ("orbit16", None), ("empty", away)]
+poses = [("start", pkg.IDENTITY), ("orbit5", None), ("orbit16", None), ("empty", away), ("orbit6", None), ("orbit19", None)]
 
 
 def orbit(i, n=24):
@@ -33,6 +33,8 @@ def orbit(i, n=24):
 
 poses[1] = ("orbit5", orbit(5))
 poses[2] = ("orbit16", orbit(16))
+poses[4] = ("orbit6", orbit(6))
+poses[5] = ("orbit19", orbit(19))
 stream = torch.cuda.current_stream()
 for W, H in sizes:
     sc = pkg.Scene.load_from_file(os.path.join(ROOT, "scenes", SCENE + ".yml")).set_size(W, H)

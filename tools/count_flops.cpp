@@ -134,6 +134,8 @@ int main()
     const long cull_record_ops = ops([&] { rec = cull_record(us, ball); });
     const long cull_shadow_directional = ops([&] { g_sink = crec_relevant(rec, D3{dir_light.sdir[0], dir_light.sdir[1], dir_light.sdir[2]}, dir_light.inv_uu, dir_light.len_u); });
     const long cull_shadow_point = ops([&] { g_sink = sphere_relevant<true>(us, ball, pt_light); });
+    const BoxH boxh{0.3, 0.2, 0.9, 0.0};
+    const long cull_shadow_box = ops([&] { g_sink = crec_in_box_shadow(rec, boxh, D3{dir_light.sdir[0], dir_light.sdir[1], dir_light.sdir[2]}); });
     // --- rays
     const long primary_dir_ops = ops([&] { D3 dd = primary_dir_tab(fa, 0.05, -0.02); g_sink = dd.x > 0.0; });
     const DS pdir_ds = last();
@@ -164,8 +166,13 @@ int main()
     std::printf("  \"solve_unitsq\": %.1f,\n  \"solve_quadric\": %.1f,\n  \"solve_linear\": %ld,\n", recompute_us + solve_quadlin_mean, recompute_gq + solve_quadlin_mean, solve_linear);
     std::printf("  \"cubic_cardano\": %ld,\n  \"cubic_trig\": %ld,\n  \"cubic_quadratic\": %.1f,\n  \"cubic_linear\": %ld,\n", solve_cardano, solve_trig, solve_quadlin_mean, solve_linear);
     std::printf("  \"tile_planes\": %ld,\n", tile_planes_ops);
-    std::printf("  \"cull_tile\": %ld,\n  \"cull_primary\": %ld,\n  \"cull_shadow_directional\": %ld,\n  \"cull_shadow_point\": %ld,\n  \"cull_record\": %ld,\n", cull_tile, cull_primary,
-                cull_shadow_directional, cull_shadow_point, cull_record_ops);
+    std::printf("  \"cull_tile\": %ld,\n  \"cull_primary\": %ld,\n  \"cull_shadow_directional\": %ld,\n  \"cull_shadow_point\": %ld,\n  \"cull_record\": %ld,\n  \"cull_shadow_box\": %ld,\n", cull_tile, cull_primary,
+                cull_shadow_directional, cull_shadow_point, cull_record_ops, cull_shadow_box);
+    // the kernel tallies a box-stage evaluation as RT_BOX_EVAL_UNITS directional decisions (rt_wavefront.hip): the two must agree
+    if (cull_shadow_box > 3 * cull_shadow_directional + 2 || cull_shadow_box < 3 * cull_shadow_directional - 2) {
+        std::fprintf(stderr, "count_flops: box-stage evaluation is %ld operations, the kernel books it as 3 x %ld\n", cull_shadow_box, cull_shadow_directional);
+        return 1;
+    }
     std::printf("  \"primary_ray\": %ld,\n  \"primary_ray_cross\": %ld,\n", primary_dir_ops + mono_o + mono_d + mono_od + cone_axis_dot, primary_dir_ops + mono_o_x + mono_d_x + mono_od_x + cone_axis_dot);
     std::printf("  \"shadow_ray_considered_directional\": %ld,\n  \"shadow_ray_considered_point\": %ld,\n", backface_dot, point_backface);
     std::printf("  \"shadow_ray_traced_directional\": %ld,\n  \"shadow_ray_traced_directional_cross\": %ld,\n", mono_od + 1, mono_od_x + 1);

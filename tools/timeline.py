@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """When is the machine busy?  Per-wave start / end times of one frame (diagnostic library: make STAMPS=1 SPILLS_OK=1, run with
 MI355RT_DEBUG_COUNTERS=1): waves alive per microsecond, split by what they end up doing, and the phase shares.
-usage: python tools/timeline.py [W H [flags]]"""
+usage: python tools/timeline.py [W H [flags [orbit pose 0..23]]]"""
 import os
 import sys
 
@@ -19,8 +19,14 @@ H = int(sys.argv[2]) if len(sys.argv) > 2 else 1080
 flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 sc = pkg.Scene.load_from_file(os.path.join(ROOT, "scenes", "20spheres.yml")).set_size(W, H)
 r = pkg.Renderer(sc, device=0, flags=flags)
+cam = None
+if len(sys.argv) > 4:   # a pose of bench.py's orbit
+    a = 2.0 * np.pi * int(sys.argv[4]) / 24
+    pos = (5.0 + 14.0 * np.sin(a), 2.0 + 2.0 * np.sin(2 * a), 15.0 - 14.0 * np.cos(a))
+    cam = pkg.camera_matrix(pos, float(np.degrees(np.arctan2(15.0 - pos[2], 5.0 - pos[0]))), float(-np.degrees(np.arctan2(pos[1] - 2.0, 14.0))))
+    print(f"orbit pose {sys.argv[4]}")
 for _ in range(4):
-    ms = r.update()
+    ms = r.update(cam)
 rows = r.stamp_rows()
 row_index = np.nonzero(rows[:, 13] > 0)[0]
 rows = rows[rows[:, 13] > 0]

@@ -51,6 +51,15 @@ int fail(int code, const char *fmt, ...)
 
 enum Transport { DIRECT = 0, LOCAL_COPY = 1, RCCL = 2 };
 
+// every entry point moves the calling thread from device to device; it leaves with the device it came with
+struct DeviceRestore {
+    int d = -1;
+    DeviceRestore() { if (hipGetDevice(&d) != hipSuccess) d = -1; }
+    ~DeviceRestore() { if (d >= 0) (void) hipSetDevice(d); }
+    DeviceRestore(const DeviceRestore &) = delete;
+    DeviceRestore &operator=(const DeviceRestore &) = delete;
+};
+
 } // namespace
 
 struct rt_multi {
@@ -74,6 +83,7 @@ struct rt_multi {
 extern "C" int rt_multi_destroy(rt_multi *m)
 {
     if (!m) return RT_OK;
+    DeviceRestore restore;
     for (uint32_t r = 0; r < m->n; r++) {
         (void) hipSetDevice(m->dev[r]);
         if (r < m->s_render.size() && m->s_render[r]) (void) hipStreamSynchronize(m->s_render[r]);
@@ -189,6 +199,7 @@ extern "C" int rt_create_multi(rt_multi **out, const rt_scene_desc *scene, const
         if (devices[r] < 0 || devices[r] >= ndev) return fail(RT_ERR_INVALID, "rt_create_multi: device %d out of range (%d devices)", devices[r], ndev);
     rt_multi *m = new (std::nothrow) rt_multi();
     if (!m) return fail(RT_ERR_NOMEM, "out of memory");
+    DeviceRestore restore;
     int rc;
     try {
         rc = create_impl(m, scene, devices, n_devices, band_rows ? band_rows : 16, parts, flags, format);
@@ -208,6 +219,7 @@ extern "C" int rt_create_multi(rt_multi **out, const rt_scene_desc *scene, const
 extern "C" int rt_render_multi(rt_multi *m, const double cam[16], void *root_full_fb, float *ms)
 {
     if (!m || !cam) return fail(RT_ERR_INVALID, "rt_render_multi: null argument");
+    DeviceRestore restore;
     const uint32_t n = m->n, P = m->parts;
     void *full = root_full_fb ? root_full_fb : m->full;
     M_HIP(hipSetDevice(m->dev[0]));
@@ -238,13 +250,17 @@ extern "C" int rt_render_multi(rt_multi *m, const double cam[16], void *root_ful
             // ... and part p travels on the comm streams while part p + 1 renders
             if (m->transport == RCCL) {
                 M_NCCL(ncclGroupStart());
-                for (uint32_t r = 0; r < n; r++) {
+                ncclResult_t in_group = ncclSuccess; // a failure inside the group still closes it before this call returns
+                for (uint32_t r = 0; r < n && in_group == ncclSuccess; r++) {
                     const uint32_t q = p * n + r;
                     if (!m->local[q]) continue;
-                    M_NCCL(ncclSend(m->local[q], m->slot_bytes, ncclInt8, 0, m->comm[r], m->s_comm[r]));
-                    M_NCCL(ncclRecv((char *) m->gathered + (size_t) q * m->slot_bytes, m->slot_bytes, ncclInt8, (int) r, m->comm[0], m->s_comm[0]));
+                    in_group = ncclSend(m->local[q], m->slot_bytes, ncclInt8, 0, m->comm[r], m->s_comm[r]);
+                    if (in_group == ncclSuccess)
+                        in_group = ncclRecv((char *) m->gathered + (size_t) q * m->slot_bytes, m->slot_bytes, ncclInt8, (int) r, m->comm[0], m->s_comm[0]);
                 }
-                M_NCCL(ncclGroupEnd());
+                const ncclResult_t closed = ncclGroupEnd();
+                if (in_group != ncclSuccess) return fail(RT_ERR_DEVICE, "ncclSend / ncclRecv of part %u failed: %s", p, ncclGetErrorString(in_group));
+                M_NCCL(closed);
             } else if (m->transport == LOCAL_COPY) {
                 for (uint32_t r = 1; r < n; r++) {
                     const uint32_t q = p * n + r;
@@ -282,6 +298,7 @@ extern "C" int rt_render_multi(rt_multi *m, const double cam[16], void *root_ful
 extern "C" int rt_multi_wait(rt_multi *m)
 {
     if (!m) return fail(RT_ERR_INVALID, "rt_multi_wait: null argument");
+    DeviceRestore restore;
     M_HIP(hipSetDevice(m->dev[0]));
     M_HIP(hipStreamSynchronize(m->s_render[0]));
     return RT_OK;
@@ -295,6 +312,7 @@ extern "C" int rt_multi_download(rt_multi *m, void *host_dst, size_t bytes)
 {
     if (!m || !host_dst) return fail(RT_ERR_INVALID, "rt_multi_download: null argument");
     if (bytes > m->full_bytes) return fail(RT_ERR_INVALID, "rt_multi_download: %zu bytes requested, the frame holds %zu", bytes, m->full_bytes);
+    DeviceRestore restore;
     M_HIP(hipSetDevice(m->dev[0]));
     M_HIP(hipStreamSynchronize(m->s_render[0]));
     M_HIP(hipMemcpy(host_dst, m->full, bytes, hipMemcpyDeviceToHost));

@@ -1085,7 +1085,6 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         bool live = inside; // this pixel still has a ray to trace
         bool first = true;
         uint32_t ord_cls = 0, ord_pos = 0; // thread 0: this tile's entry in the next frame's launch order
-        uint32_t sp_pos = 0xFFFFFFFFu;     // thread 0, sparse output: this tile's slot in the message
         if (fa.sparse && tid == 0) s_sparse[0] = 0xFFFFFFFFu; // visible after the first barrier of round 0
         float cur_ratio = 1.0f;
         uint32_t n_refl = 0;
@@ -1133,7 +1132,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             const uint32_t c0 = s_wcount[0], c1 = s_wcount[1], c2 = s_wcount[2], c3 = s_wcount[3];
             const uint32_t n_hits = c0 + c1 + c2 + c3;
             if (first && fa.sparse && tid == 0 && n_hits) // sparse output: a tile with hits takes a slot of the message; the slot
-                sp_pos = atomicAdd(reinterpret_cast<uint32_t *>(fb), 1u); // number is published at phase C, used at the final store
+                s_sparse[0] = atomicAdd(reinterpret_cast<uint32_t *>(fb), 1u); // parked in LDS at once (not in a register across the shadow phase); the barriers of this round publish it before the final store
             if (first && ord_wr && tid == 0 && n_hits) { // the next frame's launch order: round-0 hits in four cost classes
                 if (((tile * 0x9E3779B1u) >> 28) == 0u) atomicAdd(&ord_wr[16], 1u); // census, also while the ordering is off
             }
@@ -1287,7 +1286,6 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             }
 
             // ---------------- phase C: shade each hit, lights in order ----------------
-            if (first && fa.sparse && tid == 0) s_sparse[0] = sp_pos; // the barrier after this phase publishes it
             if (tid < n_hits) {
                 const uint32_t h = tid;
                 const D3 p{hp[h], hp[WG + h], hp[2 * WG + h]};
@@ -1362,7 +1360,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         // the pixel's coordinates are formed again here (from an opaque copy of tid) instead of being kept in registers
         // through all the rounds; one more lever that keeps the mirror instantiations free of scratch spills
         uint32_t tid_ = tid;
-        if (HAS_MIRROR) asm volatile("" : "+v"(tid_));
+        // (no opaque copy)
         const uint32_t sx_ = (tile % fa.tiles_x) * RT_TILE + tile_px(tid_), sy_ = (tile / fa.tiles_x) * RT_TILE + tile_py(tid_);
         if (fa.sparse) { // launch-uniform: fb is a message (rt_pack_sparse's layout); only tiles with round-0 hits are in it
             const uint32_t mslot = s_sparse[0]; // workgroup-uniform

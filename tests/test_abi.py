@@ -94,10 +94,12 @@ def test_product_does_not_link_or_import_the_oracle(pkg):
 
 def test_no_kernel_spills_vgprs():
     """`make` refuses to link a library whose kernels spill VGPRs to scratch (tools/check_spills.py: with this compiler a
-    spill can be stored under a narrowed EXEC mask and reloaded under the full one); the report it leaves must say so."""
+    spill can be stored under a narrowed EXEC mask and reloaded under the full one) or reserve a private segment at all;
+    the report it leaves must say so."""
     report = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-ray-tracer_amd", "build", "spills.txt")
     if not os.path.exists(report):
         pytest.skip("library not built by this tree's Makefile")
     text = open(report).read()
-    assert "VGPR SPILL" not in text and text.strip().endswith("no VGPR spills")
+    assert "VGPR SPILL" not in text and "PRIVATE SEGMENT" not in text and text.strip().endswith("no VGPR spills, no private segment")
+    assert all(line.rstrip().endswith("scratch 0") for line in text.splitlines() if " scratch " in line)   # (a private segment costs ~0.7 us per launch)
     assert text.count("rt_wavefront") >= 32   # 16 instantiations x strict / fast

@@ -101,10 +101,12 @@ __device__ __forceinline__ uint32_t tile_py(uint32_t tid) { return (tid >> 7) * 
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR>
 constexpr int wf_occupancy()
 {
-    int occ = HAS_CUBIC ? 2 : (HAS_MIRROR ? (HAS_GQ ? 3 : 4) : (HAS_GQ ? 3 : 5)); // 95 / 128 / 168 / ~200 VGPRs (strict, no counters); the
-                                                                                  // mirror-free general-quadric one needs 129-130 at 4
+    int occ = HAS_CUBIC ? 2 : (HAS_MIRROR ? (HAS_GQ ? 3 : 4) : (HAS_GQ ? 3 : 6)); // 80 / 128 / 168 / ~200 VGPRs (strict, no counters); the
+                                                                                  // mirror-free general-quadric one needs 129-130 at 4.
+    // Spheres and planes without mirrors run at SIX workgroups per CU (80 VGPRs, and an LDS carve-up that fits six times into 160 KB:
+    // LdsLayout): same-box A/B against five -- 1080p 46.2 -> 44.3 us, 4K 127.6 -> 119.2, 8K 474 -> 428, orbit pose 19 59.2 -> 54.8.
     if (!HAS_CUBIC && RT_FAST && !COUNT) occ -= 1;  // the FMA build's different schedule needs a few registers more
-    if (!HAS_CUBIC && COUNT) occ -= 2;              // 8 + 18 counters in registers; counting renders are not timed
+    if (!HAS_CUBIC && COUNT) occ -= (HAS_GQ || HAS_MIRROR) ? 2 : 3; // 8 + 18 counters in registers; counting renders are not timed
     if (HAS_CUBIC && COUNT) occ = 1;                // counting builds inline the cubic path (they report its solver branch)
     if (!HAS_CUBIC && COUNT && RT_FAST && HAS_MIRROR) occ -= 1;
     occ += RT_WF_OCC_DELTA;
@@ -600,8 +602,8 @@ struct LdsLayout {
         hn = off; off = align16(off + 3 * WG * 8);
         hdir = off; off = align16(off + (has_mirror ? 3 * WG * 8 : 0)); // mirrors only: the pixel's incoming direction ...
         park = off; off = align16(off + (has_mirror ? 5 * WG * 4 : 0)); // ... and its running colour / ratio / depth, parked across B and C
-        hidx = off; off = align16(off + WG * 4);
-        hpix = off; off = align16(off + WG * 4);
+        hidx = off; off = align16(off + WG * 4); // (object << 8) | owner lane
+        hpix = hidx;
         color = off; off = align16(off + 3 * WG * 4);
         shadow = off; off = align16(off + WG * shadow_words * 4);
         ball = off; off = align16(off + 4 * (uint32_t) sizeof(Ball));
@@ -844,8 +846,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     double *hp = reinterpret_cast<double *>(smem + L.hp);   // [3][WG] hit points (SoA: lane-consecutive, conflict-free)
     double *hn = reinterpret_cast<double *>(smem + L.hn);   // [3][WG] hit normals
     double *hdir = reinterpret_cast<double *>(smem + L.hdir); // [3][WG] ray direction of the pixel, parked across phases B / C (mirrors only)
-    uint32_t *hidx = reinterpret_cast<uint32_t *>(smem + L.hidx); // object of hit h
-    uint32_t *hpix = reinterpret_cast<uint32_t *>(smem + L.hpix); // owner lane (pixel) of hit h
+    uint32_t *hidx = reinterpret_cast<uint32_t *>(smem + L.hidx); // (object of hit h << 8) | its owner lane (pixel)
     float *scolor = reinterpret_cast<float *>(smem + L.color);    // [3][WG] direct lighting of the pixel's hit this round
     float *spark = reinterpret_cast<float *>(smem + L.park);      // [5][WG] mirrors: running colour, blend ratio, depth of the pixel
     uint32_t *sshadow = reinterpret_cast<uint32_t *>(smem + L.shadow); // [WG][shadow_words] bit l: light l is blocked
@@ -855,6 +856,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     uint32_t *s_wcount = reinterpret_cast<uint32_t *>(smem + L.misc); // [4] hits found by each wave this round
     uint32_t *s_live = s_wcount + 4;                                  // [4] per-wave "still bouncing" flags
     uint32_t *s_sparse = s_wcount + 8;                                // [1] sparse output: this tile's slot in the message (or none)
+    uint32_t *s_zero = s_wcount + 10;                                 // [1] always 0 (see the final store)
     uint32_t *s_cost = s_wcount + 9;                                  // [1] round 0: work of the shadow phase, for the next frame's launch order
 
     RT_STAMP_DECL
@@ -1086,6 +1088,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         bool first = true;
         uint32_t ord_cls = 0, ord_pos = 0; // thread 0: this tile's entry in the next frame's launch order
         if (fa.sparse && tid == 0) s_sparse[0] = 0xFFFFFFFFu; // visible after the first barrier of round 0
+        if (tid == 0) s_zero[0] = 0u;
         float cur_ratio = 1.0f;
         uint32_t n_refl = 0;
         if (inside) cnt.add(0);
@@ -1151,8 +1154,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 my_slot = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u) + (uint32_t) __popcll(hm & ((1ull << lane) - 1ull));
                 hp[my_slot] = sp.x; hp[WG + my_slot] = sp.y; hp[2 * WG + my_slot] = sp.z;
                 hn[my_slot] = sn.x; hn[WG + my_slot] = sn.y; hn[2 * WG + my_slot] = sn.z;
-                hidx[my_slot] = (uint32_t) best;
-                hpix[my_slot] = tid;
+                hidx[my_slot] = ((uint32_t) best << 8) | tid; // object of hit h, its owner lane (pixel) in the low byte
                 if (HAS_MIRROR) { // the bounce needs the incoming direction again in phase D; keep it out of registers meanwhile
                     hdir[tid] = dir.x; hdir[WG + tid] = dir.y; hdir[2 * WG + tid] = dir.z;
                 }
@@ -1261,8 +1263,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     mono_set_od<NEED_CROSS>(sm);
                     if (wanted) cnt.traced();
                     const int blocker = lt_spherical
-                        ? shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, true>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, sbox + c, screc + c * L.n_crec, lt, lane, cnt)
-                        : shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, false>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, sbox + c, screc + c * L.n_crec, lt, lane, cnt);
+                        ? shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, true>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, sbox + c, reinterpret_cast<const CullRec *>(smem + (L.crec + c * L.n_crec * (uint32_t) sizeof(CullRec))), lt, lane, cnt)
+                        : shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, false>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, sbox + c, reinterpret_cast<const CullRec *>(smem + (L.crec + c * L.n_crec * (uint32_t) sizeof(CullRec))), lt, lane, cnt);
                     if (valid) {
                         // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
                         cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
@@ -1290,7 +1292,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 const uint32_t h = tid;
                 const D3 p{hp[h], hp[WG + h], hp[2 * WG + h]};
                 const D3 n{hn[h], hn[WG + h], hn[2 * WG + h]};
-                const MatEntry mt = S.mat[hidx[h]];
+                const uint32_t hinfo = hidx[h];
+                const MatEntry mt = S.mat[hinfo >> 8];
                 const F3 aop{mt.albedo[0] / PI_F, mt.albedo[1] / PI_F, mt.albedo[2] / PI_F}; // object_color / pi, once per hit
                 F3 acc{0.0f, 0.0f, 0.0f};
                 for (uint32_t l = 0; l < fa.n_lights; l++) {
@@ -1304,7 +1307,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                         acc.z += col.z;
                     }
                 }
-                const uint32_t px = hpix[h];
+                const uint32_t px = hinfo & 255u;
                 scolor[px] = (acc.x < 1.0f) ? acc.x : 1.0f; // glm::min(vec3(1.0f), acc)
                 scolor[WG + px] = (acc.y < 1.0f) ? acc.y : 1.0f;
                 scolor[2 * WG + px] = (acc.z < 1.0f) ? acc.z : 1.0f;
@@ -1326,7 +1329,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 const F3 oc{scolor[tid], scolor[WG + tid], scolor[2 * WG + tid]};
                 if (first) res = oc;
                 else blend(res, cur_ratio, oc);
-                const float refl = HAS_MIRROR ? S.mat[hidx[my_slot]].refl : 0.0f; // `best` is not kept across B / C
+                const float refl = HAS_MIRROR ? S.mat[hidx[my_slot] >> 8].refl : 0.0f; // `best` is not kept across B / C
                 if (!HAS_MIRROR || !((double) refl > EPS)) {
                     live = false;
                 } else {
@@ -1359,27 +1362,31 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
 
         // the pixel's coordinates are formed again here (from an opaque copy of tid) instead of being kept in registers
         // through all the rounds; one more lever that keeps the mirror instantiations free of scratch spills
-        uint32_t tid_ = tid;
-        // (no opaque copy)
-        const uint32_t sx_ = (tile % fa.tiles_x) * RT_TILE + tile_px(tid_), sy_ = (tile / fa.tiles_x) * RT_TILE + tile_py(tid_);
-        if (fa.sparse) { // launch-uniform: fb is a message (rt_pack_sparse's layout); only tiles with round-0 hits are in it
+        // ... and so are the frame's sizes: read through a fresh pointer to the arguments, they are short-lived scalar loads here instead of
+        // SGPRs (or, as it happened, a spill slot that was rematerialised away but still cost the kernel a private segment) across all phases
+        // (Only where registers are the limit -- spheres and planes without mirrors, six workgroups per CU; the other instantiations lose a per cent with it.)
+        constexpr bool LEAN = !HAS_GQ && !HAS_CUBIC && !HAS_MIRROR;
+        const FrameArgs &fe = LEAN ? cold_args().fa : fa;
+        const uint32_t tid_ = LEAN ? tid ^ s_zero[0] : tid; // (an LDS word that is always 0: the compiler cannot know, so it cannot keep x / y of round 0 alive instead)
+        const uint32_t sx_ = (tile % fe.tiles_x) * RT_TILE + tile_px(tid_), sy_ = (tile / fe.tiles_x) * RT_TILE + tile_py(tid_);
+        if (fe.sparse) { // launch-uniform: fb is a message (rt_pack_sparse's layout); only tiles with round-0 hits are in it
             const uint32_t mslot = s_sparse[0]; // workgroup-uniform
             uint32_t *msg = reinterpret_cast<uint32_t *>(fb);
-            if (mslot < fa.sparse_cap) {
+            if (mslot < fe.sparse_cap) {
                 uchar4 px;
                 px.x = (unsigned char) (int) (res.x * 255.0f + 0.5f);
                 px.y = (unsigned char) (int) (res.y * 255.0f + 0.5f);
                 px.z = (unsigned char) (int) (res.z * 255.0f + 0.5f);
                 px.w = 255;
-                const uint32_t off_tiles = (4u + fa.sparse_cap + 3u) & ~3u;
+                const uint32_t off_tiles = (4u + fe.sparse_cap + 3u) & ~3u;
                 reinterpret_cast<uchar4 *>(msg + off_tiles)[(size_t) mslot * 256u + tile_py(tid_) * 16u + tile_px(tid_)] = px;
                 if (tid == 0) msg[4u + mslot] = tile;
             } else if (mslot != 0xFFFFFFFFu && tid == 0) {
                 msg[1] = 1u; // more tiles with hits than the message holds
             }
-        } else if (sx_ < fa.width && sy_ < fa.local_rows) {
-            const size_t pix = (size_t) sy_ * fa.width + sx_;
-            if (fa.rgba8) {
+        } else if (sx_ < fe.width && sy_ < fe.local_rows) {
+            const size_t pix = (size_t) sy_ * fe.width + sx_;
+            if (fe.rgba8) {
                 uchar4 px;
                 px.x = (unsigned char) (int) (res.x * 255.0f + 0.5f);
                 px.y = (unsigned char) (int) (res.y * 255.0f + 0.5f);
@@ -1390,9 +1397,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 reinterpret_cast<float4 *>(fb)[pix] = make_float4(res.x, res.y, res.z, 1.0f);
             }
         }
-        if (ord_cls && ord_pos < fa.n_tiles) { // thread 0 of a tile with hits, ordering on (the bound can only fail if frames
+        if (ord_cls && ord_pos < fe.n_tiles) { // thread 0 of a tile with hits, ordering on (the bound can only fail if frames
                                                 // were replayed with stale arguments, e.g. from a captured graph: stay in bounds)
-            ord_wr[RT_ORD_HDR + ord_cls * fa.n_tiles + ord_pos] = tile; // ord_cls = class + 1
+            ord_wr[RT_ORD_HDR + ord_cls * fe.n_tiles + ord_pos] = tile; // ord_cls = class + 1
             ord_wr[RT_ORD_HDR + tile] = (ord_pos << 5) | ord_cls;
         }
         RT_STAMP(10);

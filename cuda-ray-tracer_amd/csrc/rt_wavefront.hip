@@ -105,7 +105,8 @@ constexpr int wf_occupancy()
                                                                                   // mirror-free general-quadric one needs 129-130 at 4.
     // Spheres and planes without mirrors run at SIX workgroups per CU (80 VGPRs, and an LDS carve-up that fits six times into 160 KB:
     // LdsLayout): same-box A/B against five -- 1080p 46.2 -> 44.3 us, 4K 127.6 -> 119.2, 8K 474 -> 428, orbit pose 19 59.2 -> 54.8.
-    if (!HAS_CUBIC && RT_FAST && !COUNT) occ -= 1;  // the FMA build's different schedule needs a few registers more
+    if (!HAS_CUBIC && RT_FAST && !COUNT && (HAS_GQ || !HAS_MIRROR)) occ -= 1; // the FMA build's different schedule needs a few registers more
+                                                                                // (not the spheres-with-mirrors one: 128 at 4, and 3 costs it 20 %)
     if (!HAS_CUBIC && COUNT) occ -= (HAS_GQ || HAS_MIRROR) ? 2 : 3; // 8 + 18 counters in registers; counting renders are not timed
     if (HAS_CUBIC && COUNT) occ = 1;                // counting builds inline the cubic path (they report its solver branch)
     if (!HAS_CUBIC && COUNT && RT_FAST && HAS_MIRROR) occ -= 1;

@@ -35,6 +35,8 @@ poses[1] = ("orbit5", orbit(5))
 poses[2] = ("orbit16", orbit(16))
 poses[4] = ("orbit6", orbit(6))
 poses[5] = ("orbit19", orbit(19))
+for extra in [int(v) for v in os.environ.get("AB_ORBIT", "").split(",") if v]:   # AB_ORBIT=7,20: further poses of the orbit
+    poses.append((f"orbit{extra}", orbit(extra)))
 stream = torch.cuda.current_stream()
 for W, H in sizes:
     sc = pkg.Scene.load_from_file(os.path.join(ROOT, "scenes", SCENE + ".yml")).set_size(W, H)
@@ -61,7 +63,7 @@ for W, H in sizes:
             img = fb.cpu().numpy()
             if ref is None:
                 ref = img
-            out.append(f"{n} {np.median(ts):8.1f} us{'' if np.array_equal(img, ref) else ' (FRAME DIFFERS)'}")
+            out.append(f"{n} {np.median(ts):8.1f} us{'' if np.array_equal(img, ref) else ' (FRAME DIFFERS)'}" + (f" batches {' '.join(f'{t:.1f}' for t in ts)}" if os.environ.get("AB_BATCHES") else ""))
         print(f"{W}x{H} {pname:8s} " + "   ".join(out), flush=True)
     for _, r in rens:
         r.cleanup_update()

@@ -590,15 +590,18 @@ def run_rank(args, world):
             for _ in range(6):   # the launch-order feedback settles on the new view: a few frames, each seen by the host before the next is issued
                 main.ren.update(cam, dev_fb=main.local[0].data_ptr(), stream=main.stream.cuda_stream, timed=False)
                 main.stream.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(main.stream)
-            for _ in range(20):
-                main.ren.update(cam, dev_fb=main.local[0].data_ptr(), stream=main.stream.cuda_stream, timed=False)
-            e1.record(main.stream)
-            e1.synchronize()
-            ts.append(e0.elapsed_time(e1) / 20.0)
+            batches = []
+            for _ in range(3):   # median of three batches: one host hiccup while enqueuing (tens of ms on a busy box) would otherwise own the pose
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main.stream)
+                for _ in range(10):
+                    main.ren.update(cam, dev_fb=main.local[0].data_ptr(), stream=main.stream.cuda_stream, timed=False)
+                e1.record(main.stream)
+                e1.synchronize()
+                batches.append(e0.elapsed_time(e1) / 10.0)
+            ts.append(float(np.median(batches)))
         ts = np.array(ts) * 1e3
-        orbit = {"poses": n_orbit, "what": "steady-state time per frame at each pose of an orbit around the scene, measured like the headline (6 settling frames, then 20 frames of the pose issued back to back, "
+        orbit = {"poses": n_orbit, "what": "steady-state time per frame at each pose of an orbit around the scene, measured like the headline (6 settling frames, then the median of three batches of 10 frames issued back to back, "
                  "one HIP event pair on the render stream); `--camera orbit` times a camera that moves every frame instead",
                  "median_us": float(np.median(ts)), "max_us": float(ts.max()), "min_us": float(ts.min())}
 

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Moving-camera sequence: the reference host's camera flies an orbit around the 20spheres
 scene; time per frame for each pose.  Culling and hit density change with the view, so this shows how stable
-the frame time is away from the start-up pose that bench.py uses.  `us` = per frame of 20 frames of the pose issued back to back
-(one HIP event pair: how bench.py times its headline); `alone` = one frame into an idle GPU with a host synchronisation after it."""
+the frame time is away from the start-up pose that bench.py uses.  `us` = per frame of 10 frames of the pose issued back to back
+(one HIP event pair: how bench.py times its headline), median of three such batches; `alone` = one frame into an idle GPU with a host synchronisation after it."""
 import os
 import sys
 
@@ -17,7 +17,7 @@ pkg = graft.load_package()
 W, H = 1920, 1080
 sc = pkg.Scene.load_from_file(os.path.join(ROOT, "scenes", "20spheres.yml")).set_size(W, H)
 r = pkg.Renderer(sc, device=0)
-rc = pkg.Renderer(sc, device=0, flags=pkg.RT_FLAG_COUNT)
+rc = pkg.Renderer(sc, device=0, flags=pkg.RT_FLAG_COUNT) if not os.environ.get("FLY_NO_COUNT") else None
 stream = torch.cuda.current_stream()
 print(f"{'frame':>5} {'pos':>24} {'yaw':>6} {'pitch':>6} {'us':>8} {'alone':>7} {'hits':>8} {'rays':>9} {'Mrays/s':>9} {'exec':>9} {'solves':>8} {'culls':>8}")
 ts = []
@@ -30,15 +30,19 @@ for i in range(24):
     for _ in range(3):   # the launch-order feedback settles on the new view
         r.update(cam)
     alone = np.median([r.update(cam) for _ in range(5)])
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(20):
-        r.update(cam, stream=stream.cuda_stream, timed=False)
-    e1.record(stream)
-    e1.synchronize()
-    t = e0.elapsed_time(e1) / 20.0
-    rc.update(cam)
-    c = rc.counters()
+    batches = []
+    for _ in range(3):   # median of three batches (a host hiccup while enqueuing would otherwise own the pose)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(10):
+            r.update(cam, stream=stream.cuda_stream, timed=False)
+        e1.record(stream)
+        e1.synchronize()
+        batches.append(e0.elapsed_time(e1) / 10.0)
+    t = float(np.median(batches))
+    if rc is not None:
+        rc.update(cam)
+    c = rc.counters() if rc is not None else dict(hits=0, rays_total=0, tests_executed=0, solves=0, cull_evals=0)
     ts.append(t)
     print(f"{i:5d} ({pos[0]:7.2f},{pos[1]:6.2f},{pos[2]:7.2f}) {yaw:6.1f} {pitch:6.1f} {t*1e3:8.1f} {alone*1e3:7.1f} {c['hits']:8d} {c['rays_total']:9d} {c['rays_total']/t/1e3:9.0f} {c['tests_executed']:9d} {c['solves']:8d} {c['cull_evals']:8d}")
 ts = np.array(ts)

@@ -277,7 +277,12 @@ class FramePath:
         self.px_dtype, self.px_bytes = (torch.uint8, 4) if fmt_name == "rgba8" else (torch.float32, 16)
         self.ren = pkg.Renderer(env["scene"], device=env["local_rank"], rank=self.rank, world=self.world, band_rows=args.band_rows, flags=env["flags"], fmt=self.fmt)
         self.mx = self.ren.max_local_rows
-        self.stream = torch.cuda.current_stream(self.dev)
+        if self.dist_on:
+            self.stream = torch.cuda.current_stream(self.dev)
+        else:   # N = 1: a stream of its own, so that the K timed frames can be captured into one hipGraph (run_timed)
+            self.stream = torch.cuda.Stream(device=self.dev)
+            torch.cuda.set_stream(self.stream)
+        self.timed_region = "K launches"
         W, H, dev, world = self.W, self.H, self.dev, self.world
         nb = 2 if self.dist_on else 1
         self.sparse = self.dist_on and gather_kind == "sparse" and fmt_name == "rgba8"
@@ -447,11 +452,31 @@ class FramePath:
         self.kernel_events = []
         if self.dist_on:
             dist.barrier()
+        # N = 1: the K frames are captured into ONE hipGraph before the clock starts and the timed region launches that graph: the
+        # same K kernels with the same arguments, but the GPU no longer waits for the host between them.  (The host enqueues a frame in
+        # 8 us and the GPU renders it in 45, so normally the queue is never empty -- but on a shared box the enqueuing thread is
+        # descheduled for tens of ms now and then (tools/spike_probe.py: two 40 ms stalls in 4 500 frames), and one such stall inside a
+        # 200-frame region would be reported as a 5x slower frame.)  --no-graph, or a failed capture, times K plain launches.
+        graph = None
+        if not self.dist_on and not self.env["args"].no_graph and len(self.cams) == 1:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=self.stream):
+                    for _ in range(steps):
+                        self.step()
+                self.timed_region = f"one hipGraph of the K = {steps} frame launches, captured before the clock starts"
+            except Exception as exc:   # (capture not possible here: fall back, and say so)
+                graph = None
+                self.timed_region = f"K launches (graph capture failed: {type(exc).__name__})"
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev0.record(self.stream)
-        for _ in range(steps):
-            self.step()
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(steps):
+                self.step()
         self.flush()
         ev1.record(self.stream)
         torch.cuda.synchronize()
@@ -567,6 +592,14 @@ def run_rank(args, world):
     rays_timed = rays_in(args.steps, args.warmup)
     check_main = main.frame_check()
     gather_main = main.gather_report() if dist_on else None
+    timed_frame_ok = None
+    if not dist_on and len(cams) == 1:   # the last frame of the timed region (graph or not) against one more plain launch of the same frame
+        last = main.local[0].clone()
+        main.ren.update(cams[0], dev_fb=main.local[0].data_ptr(), stream=main.stream.cuda_stream, timed=False)
+        main.stream.synchronize()
+        timed_frame_ok = bool(torch.equal(last, main.local[0]))
+        if not timed_frame_ok:
+            raise SystemExit("bench.py: the last frame of the timed region differs from a plain launch of the same frame")
 
     # ---- N > 1: the display wire format (RGBA8, sparse tiles) timed the same way, reported next to the headline ----
     alt = None
@@ -628,7 +661,7 @@ def run_rank(args, world):
                 "traffic_source": (f"{pmc['source']} (committed PMC passes of this command; not measured by this run)" if pmc and not pmc.get("stale") else
                                    ("PMC summary is older than the kernel sources: dropped" if pmc else None)),
                 "kernel": "trace_tile_kernel" if args.kernel == "simple" else "wavefront_tile_kernel",
-                "kernel_ms": kernel_ms, "kernel_ms_source": "HIP events on the render stream inside the timed region",
+                "kernel_ms": kernel_ms, "kernel_ms_source": "HIP events on the render stream inside the timed region", "timed_region": main.timed_region, "timed_region_last_frame_identical_to_plain_launch": timed_frame_ok,
                 "algorithmic_flops_per_launch": flops_launch, "algorithmic_flops_source": f"{table_src} (counting scalar over the kernel's own math) x device work counters by surface class",
                 "capped_at_dense_reference_count": capped, "dense_reference_flops_per_launch": dense_local,
                 "work_units_per_launch": {k: v for k, v in cnt.items()},
@@ -734,6 +767,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="N = 1: run the N > 1 code path (process group, gather, reassembly) with one rank")
     ap.add_argument("--no-alt", action="store_true")
     ap.add_argument("--no-orbit", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="N = 1: time K plain launches instead of one hipGraph of them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     args = ap.parse_args()

@@ -77,3 +77,17 @@ def test_sparse_overflow_is_resent_densely():
     alt = r["config"]["alt"]
     assert alt["gather"]["frames_resent_densely"] >= 1
     assert alt["gathered_frame_identical_to_single_gpu_frame"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [True, False])
+def test_timed_region_as_one_graph_or_as_plain_launches(graph):
+    """N = 1: the K timed frames are launched as one captured hipGraph (default) or one by one (--no-graph); either way the JSON
+    line says which, and the last frame of the timed region equals a plain launch of the same frame."""
+    p = _run(["--steps", "7", "--warmup", "3", "--no-orbit", "--no-cpu-baseline"] + ([] if graph else ["--no-graph"]))
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    roof = r["roofline"]
+    assert roof["timed_region"].startswith("one hipGraph of the K = 7 frame launches" if graph else "K launches")
+    assert roof["timed_region_last_frame_identical_to_plain_launch"] is True
+    assert r["steps"] == 7 and r["n_gpus"] == 1 and roof["kernel_ms"] > 0

@@ -976,6 +976,10 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     }
 #endif
     {
+        // (the frame's sizes, asked for together: the compiler fetches kernel arguments again rather than keep them in SGPRs, and left to
+        // itself it does so one branch at a time -- each a scalar round trip on every tracing workgroup's way to its first ray)
+        asm volatile("" ::"s"(fa.width), "s"(fa.local_rows), "s"(fa.tiles_x), "s"(fa.band_rows), "s"(fa.rank), "s"(fa.world), "s"(fa.all_cullable),
+                     "s"(fa.tile_planes_ok));
         // pixel of this lane: each wave covers an 8 x 8 quadrant of the tile (tile_px / tile_py)
         const uint32_t tile_x = tile % fa.tiles_x, tile_y = tile / fa.tiles_x;
         const uint32_t x = tile_x * RT_TILE + tile_px(tid), lr = tile_y * RT_TILE + tile_py(tid);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """All five BASELINE configs on one GPU: frame time, frames/s, Mrays/s, parity summary vs the oracle on a row sample.
-`us` is the time per frame of frames issued back to back on one stream (one HIP event pair around the batch: what bench.py times);
+`us` is the time per frame of frames issued back to back on one stream, single launches (one HIP event pair around the batch; bench.py's
+headline launches its timed frames as one hipGraph, which saves the ~3 us between two dependent launches: 42.2 instead of 43.6-45 us for config 2);
 `alone` is one frame rendered into an idle GPU with a host synchronisation after it (event pair around that launch)."""
 import os
 import sys

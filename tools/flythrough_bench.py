@@ -2,7 +2,7 @@
 """Moving-camera sequence: the reference host's camera flies an orbit around the 20spheres
 scene; time per frame for each pose.  Culling and hit density change with the view, so this shows how stable
 the frame time is away from the start-up pose that bench.py uses.  `us` = per frame of 10 frames of the pose issued back to back
-(one HIP event pair: how bench.py times its headline), median of three such batches; `alone` = one frame into an idle GPU with a host synchronisation after it."""
+(one HIP event pair, single launches), median of three such batches; `alone` = one frame into an idle GPU with a host synchronisation after it."""
 import os
 import sys
 

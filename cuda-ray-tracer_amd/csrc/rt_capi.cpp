@@ -110,6 +110,7 @@ struct rt_ctx {
     uint32_t frame = 0; // renders so far: selects the launch-order generation (FrameArgs::order_state)
     uint32_t tag = 0;   // frame tag of the scan workgroups' tile words (FrameArgs::tile_state); unique per render, never 0
     uint32_t *h_listed = nullptr; // host-mapped words the kernel writes (FrameArgs::ord_host)
+    uint32_t ord_split = 0;       // FrameArgs::ord_split of non-sparse frames
     bool ord_on = true;           // launch-order feedback in use (off while most tiles have hits)
 };
 
@@ -379,6 +380,8 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
     fa.n_tiles = fa.tiles_x * ((ctx->local_rows + RT_TILE - 1) / RT_TILE);
     fa.rgba8 = cfg.format == RT_FMT_RGBA8 ? 1u : 0u;
     fa.ord_plain = (cfg.flags & RT_FLAG_PLAIN_ORDER) ? 1u : 0u;
+    ctx->ord_split = (cfg.flags & RT_FLAG_NOSPLIT) ? 0u : RT_ORD_SPLIT_CLASSES;
+    if (const char *e = std::getenv("MI355RT_SPLIT_CLASSES")) ctx->ord_split = (uint32_t) std::atoi(e) & 15u; // (experiments)
     fa.has_mirror = 0;
     for (uint32_t i = 0; i < sd->n_objects; i++)
         if ((double) sd->reflection[i] > 1e-7) fa.has_mirror = 1; // EPS of the reflection loop, src/update-cpu.cpp:101
@@ -533,7 +536,8 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
         if (rc == RT_OK && !(cfg.flags & (RT_FLAG_SIMPLE | RT_FLAG_STATIC_ORDER)) && fa.n_tiles > 0 && fa.n_tiles <= RT_ORD_MAX_TILES) {
             // launch-order feedback: three generations, all empty (first frame = index order)
             fa.ord_stride = (RT_ORD_HDR + 17u * fa.n_tiles + 15u) & ~15u;
-            const size_t bytes = sizeof(uint32_t) * 3u * fa.ord_stride;
+            // ... and behind them one word per tile, the last frame in which one of a split tile's two workgroups entered the tile (FrameArgs::ord_frame)
+            const size_t bytes = sizeof(uint32_t) * (3u * (size_t) fa.ord_stride + fa.n_tiles);
             hip_ok(hipMalloc((void **) &fa.order_state, bytes), "hipMalloc(order)") && hip_ok(hipMemset(fa.order_state, 0, bytes), "hipMemset(order)");
             // the kernel reports the number of listed tiles through one host-mapped word; without it (allocation
             // refused) every launch simply carries n_tiles list slots
@@ -649,6 +653,8 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
         }
         fa.ord_cap = cap;
         fa.ord_on = ctx->ord_on ? 1u : 0u;
+        fa.ord_split = fa.sparse ? 0u : ctx->ord_split; // (a sparse message has one slot per tile)
+        fa.ord_frame = ctx->frame + 1u;                 // never 0 (the words start out 0); wraps after 2^32 frames
         ctx->frame++;
     }
     if (ms) RT_HIP(hipEventRecord(ctx->ev0, stream));

@@ -130,6 +130,10 @@ struct FrameArgs {
     uint32_t ord_cap;     // list slots in this launch (the grid is n_scan + ord_cap + n_tiles workgroups)
     uint32_t ord_on;      // 0: index order this frame, census only
     uint32_t ord_plain;   // 1: RT_FLAG_PLAIN_ORDER (A/B): list slot q renders list entry q instead of the balanced (snake) assignment
+    uint32_t ord_frame;   // this frame's number (never 0): order_state[3 * ord_stride + t] remembers the last frame in which a half-tile workgroup
+                          // entered tile t into the lists, so that exactly one of the two does
+    uint32_t ord_split;   // the tiles of this many of the costliest cost classes (0..15) are rendered by two workgroups, one per half tile
+                          // (rt_wavefront.hip, "half tiles"); 0 with sparse output (a tile is one message slot) and RT_FLAG_NOSPLIT
     // Tile words (all_cullable scenes; rt_wavefront.hip, "tile words"): the first n_scan workgroups of the grid classify
     // RT_SCAN_TILES tiles each and publish tile_state[t] = (frame_tag << 3) | EMPTY / NONEMPTY / COVERED, paint workgroups paint the
     // EMPTY ones, and the workgroup that gets tile t in index order leaves at once when the word says EMPTY.
@@ -141,6 +145,7 @@ struct FrameArgs {
 #define RT_TILE 16        // a workgroup renders a 16 x 16 pixel tile
 #define RT_SCAN_TILES 64  // tiles classified by one classifying workgroup: sixteen per wave
 #define RT_PAINT_TILES 16 // tiles one paint workgroup is responsible for: four per wave
+#define RT_ORD_SPLIT_CLASSES 8u /* default FrameArgs::ord_split: tiles that cost more than half of the costliest one */
 #define RT_ORD_HDR 32      // words before word[] in one generation of FrameArgs::order_state
 #define RT_ORD_MAX_TILES 262144u // 8K frames (129 600 tiles) included: the order still pays there (measured), the state is 20 B per tile and generation
 

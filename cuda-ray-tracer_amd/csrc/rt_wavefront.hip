@@ -259,10 +259,14 @@ constexpr uint32_t ORD_CLASSES = 16;
 struct OrdHeader {
     uint32_t cnt[ORD_CLASSES];
     uint32_t census, cost_max, n_listed;
+    uint32_t n_candidates; // entries of the `split` costliest classes (what the host sizes the list slots for: the decision below may change from frame to frame)
+    uint32_t n_heavy;      // those of them that ARE split this frame: each is rendered by TWO list slots, one per half tile (below)
 };
+// `split_arg` = (workgroup slots of the GPU for this kernel << 4) | cost classes that may be split (bits 4-7 and 20-31 of hot_flags)
 template <typename Words>
-__device__ __forceinline__ OrdHeader ord_header(Words rd)
+__device__ __forceinline__ OrdHeader ord_header(Words rd, uint32_t split_arg = 0)
 {
+    const uint32_t split = split_arg & 15u, slots = split_arg >> 4;
     OrdHeader h;
     h.n_listed = 0;
 #pragma unroll
@@ -270,10 +274,26 @@ __device__ __forceinline__ OrdHeader ord_header(Words rd)
         h.cnt[k] = rd[k];
         h.n_listed += h.cnt[k];
     }
+    // Half tiles.  A tile full of hits keeps its four waves busy for 19 shadow items each while a tile with 64 hits is done after five,
+    // and the frame ends when the costliest tile ends.  While the GPU has room (at most three quarters of its workgroup slots taken by
+    // whole tiles -- beyond that the frame is bound by throughput and a second workgroup per tile only adds its fixed costs), an entry
+    // of the `split` costliest classes gets TWO consecutive positions in the launch order: rows 0-7 of the tile and rows 8-15, each by
+    // a workgroup of its own whose other two waves have no pixels but take their share of the shadow items.  Positions, not entries,
+    // are what the list slots index:  position p < 2 * n_heavy -> entry p / 2, half 1 + (p & 1);  otherwise entry p - n_heavy, whole tile.
+    const uint32_t spare = slots > h.n_listed ? slots - h.n_listed : 0u;
+    h.n_heavy = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < ORD_CLASSES; k++) h.n_heavy += k < split ? h.cnt[k] : 0u;
+    if (h.n_listed * 4u > slots * 3u) h.n_heavy = 0;
+    h.n_candidates = h.n_heavy; // (none while the GPU is full: list slots that only leave again are not free there)
+    h.n_heavy = h.n_heavy < spare ? h.n_heavy : spare;
     h.census = rd[16];
     h.cost_max = rd[17];
     return h;
 }
+__device__ __forceinline__ uint32_t ord_positions(const OrdHeader &h) { return h.n_listed + h.n_heavy; }
+// last position of entry `rank`: the entry is rendered by list slots iff that position is one of the n_eff in use
+__device__ __forceinline__ uint32_t ord_last_position(const OrdHeader &h, uint32_t rank) { return rank < h.n_heavy ? 2u * rank + 1u : rank + h.n_heavy; }
 // class and index of list entry `rank` (rank < h.n_listed)
 __device__ __forceinline__ void ord_locate(const OrdHeader &h, uint32_t rank, uint32_t &k, uint32_t &idx)
 {
@@ -358,7 +378,7 @@ __device__ __forceinline__ uint32_t tile_word_wait(uint32_t *w, uint32_t tag, ui
 
 template <bool COUNT>
 __device__ __forceinline__ void classify_tiles(const FrameArgs &fa, const UsEntry *us, uint32_t n_us, uint32_t *tile_state, uint32_t tag, uint32_t n_tiles,
-                                               const uint32_t *ord_rd, uint32_t ord_cap, uint32_t wave, uint32_t lane, Cnt<COUNT> &cnt)
+                                               const uint32_t *ord_rd, uint32_t ord_cap, uint32_t ord_split, uint32_t wave, uint32_t lane, Cnt<COUNT> &cnt)
 {
     const uint32_t i = lane & 15u, sl = lane >> 4;
     const uint32_t t = blockIdx.x * RT_SCAN_TILES + wave * 16u + i;
@@ -396,8 +416,8 @@ __device__ __forceinline__ void classify_tiles(const FrameArgs &fa, const UsEntr
         uint32_t st = nonempty ? ST_NONEMPTY : ST_EMPTY;
         if (nonempty && ord_rd) { // launch-order lists in use: does a list slot of this launch render the tile?  (the test of the index slots, made here
                                   // once, so that the index slot of a covered tile leaves after one load as well)
-            const OrdHeader oh = ord_header(ord_rd);
-            const uint32_t n_eff = oh.n_listed < ord_cap ? oh.n_listed : ord_cap;
+            const OrdHeader oh = ord_header(ord_rd, ord_split); // (ord_split: classes | slots << 4)
+            const uint32_t n_eff = ord_positions(oh) < ord_cap ? ord_positions(oh) : ord_cap;
             const uint32_t w = ord_rd[RT_ORD_HDR + t]; // (position in its class list << 5) | (class + 1): a hint where to look, possibly stale
             const uint32_t cls = w & 31u, pos = w >> 5;
             if (cls >= 1u && cls <= ORD_CLASSES && pos < n_tiles) {
@@ -405,7 +425,7 @@ __device__ __forceinline__ void classify_tiles(const FrameArgs &fa, const UsEntr
                 uint32_t count = 0;
 #pragma unroll
                 for (uint32_t c = 0; c < ORD_CLASSES; c++) count = c == k ? oh.cnt[c] : count;
-                if (pos < count && ord_first(oh, k) + pos < n_eff && ord_rd[RT_ORD_HDR + (1u + k) * n_tiles + pos] == t) st = ST_COVERED;
+                if (pos < count && ord_last_position(oh, ord_first(oh, k) + pos) < n_eff && ord_rd[RT_ORD_HDR + (1u + k) * n_tiles + pos] == t) st = ST_COVERED;
             }
         }
         uint32_t expect = old;
@@ -610,7 +630,7 @@ struct LdsLayout {
         ball = off; off = align16(off + 4 * (uint32_t) sizeof(Ball));
         box = off; off = align16(off + 4 * (uint32_t) sizeof(BoxH));
         crec = off; off = align16(off + 4 * n_crec * (uint32_t) sizeof(CullRec));
-        misc = off; off = align16(off + 48);
+        misc = off; off = align16(off + 64);
         total = off;
     }
 };
@@ -858,6 +878,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     uint32_t *s_live = s_wcount + 4;                                  // [4] per-wave "still bouncing" flags
     uint32_t *s_sparse = s_wcount + 8;                                // [1] sparse output: this tile's slot in the message (or none)
     uint32_t *s_zero = s_wcount + 10;                                 // [1] always 0 (see the final store)
+    uint32_t *s_decode = s_wcount + 12;                               // [3] what wave 0 decoded from the launch order: tile, flags, cost scale
+    uint32_t *s_half = s_wcount + 11;                                 // [1] which half of the tile this workgroup renders (0: all of it)
     uint32_t *s_cost = s_wcount + 9;                                  // [1] round 0: work of the shadow phase, for the next frame's launch order
 
     RT_STAMP_DECL
@@ -873,7 +895,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
 
     if (ALL_SPHERES_POSSIBLE && role == 1) { // workgroup-uniform
         classify_tiles<COUNT>(fa, reinterpret_cast<const UsEntry *>(hot_us), hot_n_us, hot_tile_state, hot_frame_tag, hot_n_tiles,
-                              (hot_flags & 2u) ? hot_ord_rd : nullptr, hot_ord_cap, wave, lane, cnt);
+                              (hot_flags & 2u) ? hot_ord_rd : nullptr, hot_ord_cap, ((hot_flags >> 4) & 15u) | ((hot_flags >> 20) << 4), wave, lane, cnt);
         RT_STAMP(11);
         RT_STAMP_FLUSH(counters, lane);
         cnt.flush(counters);
@@ -912,6 +934,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     uint32_t *ord_wr = nullptr;
     uint32_t tile = slot;
     bool listed = false;  // this tile had hits in the previous frame
+    uint32_t half = 0;    // list slots of the costliest entries: 1 = rows 0-7 of the tile only, 2 = rows 8-15 only (0: the whole tile)
     bool listing = false; // this frame appends to the lists
     uint32_t cost_scale = 0; // largest tile cost of the previous frame: the scale of the cost classes
     bool covered = false; // index-order slot whose tile a list slot renders: leaves before its first side effect
@@ -925,49 +948,70 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         }
     }
     if (hot_flags & 2u) { // launch-uniform
-        // the generation being read was written by the previous launch and is not touched by this one: constant address
-        // space, so that the reads become scalar loads (through the generic pointer they are vector loads + readfirstlane)
-        typedef const __attribute__((address_space(4))) uint32_t *ConstWords;
-        ConstWords ord_rd = (ConstWords) hot_ord_rd;
+        // ONE wave decodes the launch order for the workgroup and hands the result to the other three through LDS.  The decode is a
+        // few hundred scalar instructions (sixteen class counts: sums, a search, a rank), a CU has ONE scalar unit, and at the start of a
+        // frame all 24 waves of a CU are here at once: with every wave decoding for itself the set-up phase was bound by that unit
+        // (~13 000 scalar issue cycles per CU, the 5 us every tracing workgroup spent before its first ray; measured: 70 more scalar
+        // instructions per wave cost 1 700 cycles per wave).
         ord_wr = fa.order_state + (size_t) fa.ord_write * fa.ord_stride;
-        const OrdHeader oh = ord_header(ord_rd); // listed tiles per cost class, census (tiles with hits in the previous frame, 1 in 16 counted), largest cost
-        // the per-tile word of an index-order slot is requested with them (for a list slot: tile 0's, unused)
-        const uint32_t idx_tile = slot >= hot_ord_cap ? slot - hot_ord_cap : 0u;
-        const uint32_t w = ord_rd[RT_ORD_HDR + idx_tile]; // (position in its class list << 5) | (class + 1), 0 = had no hits
-        // ask for the camera / frame part of the kernel arguments here, between issuing the order-state reads and using
-        // them: otherwise the compiler sinks those loads below the order decode and a workgroup starts with three
-        // dependent round trips (arguments, order state, arguments again)
+        // ask for the camera / frame part of the kernel arguments here (all waves need them), before anybody waits for anything
         asm volatile("" ::"s"(fa.cam[0]), "s"(fa.cam[2]), "s"(fa.cam[5]), "s"(fa.cam[6]), "s"(fa.cam[8]), "s"(fa.cam[10]), "s"(fa.origin[0]),
                      "s"(fa.origin[2]), "s"(fa.aspect), "s"(fa.tan_half_fov), "s"(fa.width), "s"(fa.local_rows), "s"(fa.tiles_x), "s"(fa.n_us),
-                     "s"(fa.off_us), "s"(fa.band_rows), "s"(fa.all_cullable), "s"(gscene), "s"(w));
-        listing = oh.census * 64u < hot_n_tiles;                     // the host's switch lags a few frames: same rule here
-        cost_scale = oh.cost_max;
-        const uint32_t n_eff = oh.n_listed < hot_ord_cap ? oh.n_listed : hot_ord_cap;
-        if (slot == 0 && tid == 0) {
-            uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride; // the generation the NEXT frame appends to
-            for (uint32_t k = 0; k < 20; k += 4) *reinterpret_cast<uint4 *>(z + k) = make_uint4(0, 0, 0, 0);
-            if (fa.ord_host) { fa.ord_host[0] = oh.n_listed; fa.ord_host[1] = oh.census; } // host-mapped: sizes / switches later launches
-        }
-        if (slot < hot_ord_cap) {
-            if (slot >= n_eff) return; // workgroup-uniform
-            uint32_t k, idx;
-            ord_locate(oh, (hot_flags & 8u) ? slot : ord_rank_of_slot(slot, n_eff, blockIdx.x - slot), k, idx); // 8: A/B switch, entries in list order
-            tile = ord_rd[RT_ORD_HDR + (1u + k) * hot_n_tiles + idx];
-            if (tile >= hot_n_tiles) return; // never true for lists this kernel wrote; keeps a corrupted list harmless
-            listed = true;
-        } else {
-            tile = idx_tile;
-            // A tile without hits writes nothing, so its word may be left over from an older frame of this generation:
-            // the word is only a hint where to look, and the tile counts as covered iff that list entry really names it.
-            const uint32_t cls = w & 31u, pos = w >> 5;
-            if (tstate == ST_TIMEOUT && cls >= 1u && cls <= ORD_CLASSES && pos < hot_n_tiles) { // (NONEMPTY: its classifier already found it uncovered)
-                const uint32_t k = cls - 1u;
-                uint32_t count = 0;
-#pragma unroll
-                for (uint32_t c = 0; c < ORD_CLASSES; c++) count = c == k ? oh.cnt[c] : count;
-                if (pos < count && ord_first(oh, k) + pos < n_eff) covered = ord_rd[RT_ORD_HDR + (1u + k) * hot_n_tiles + pos] == tile;
+                     "s"(fa.off_us), "s"(fa.band_rows), "s"(fa.all_cullable), "s"(gscene));
+        if (wave == 0) { // wave-uniform
+            // the generation being read was written by the previous launch and is not touched by this one: constant address
+            // space, so that the reads become scalar loads (through the generic pointer they are vector loads + readfirstlane)
+            typedef const __attribute__((address_space(4))) uint32_t *ConstWords;
+            ConstWords ord_rd = (ConstWords) hot_ord_rd;
+            const OrdHeader oh = ord_header(ord_rd, ((hot_flags >> 4) & 15u) | ((hot_flags >> 20) << 4)); // listed tiles per cost class, census, largest cost, half tiles
+            // the per-tile word of an index-order slot is requested with them (for a list slot: tile 0's, unused)
+            const uint32_t idx_tile = slot >= hot_ord_cap ? slot - hot_ord_cap : 0u;
+            const uint32_t w = ord_rd[RT_ORD_HDR + idx_tile]; // (position in its class list << 5) | (class + 1), 0 = had no hits
+            const uint32_t n_eff = ord_positions(oh) < hot_ord_cap ? ord_positions(oh) : hot_ord_cap; // positions in use (half tiles count twice)
+            if (slot == 0 && lane == 0) {
+                uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride; // the generation the NEXT frame appends to
+                for (uint32_t k = 0; k < 20; k += 4) *reinterpret_cast<uint4 *>(z + k) = make_uint4(0, 0, 0, 0);
+                if (fa.ord_host) { fa.ord_host[0] = oh.n_listed + oh.n_candidates; fa.ord_host[1] = oh.census; } // host-mapped: sizes / switches later launches
             }
+            uint32_t d_half = 0;
+            uint32_t d_tile = slot, d_flags = oh.census * 64u < hot_n_tiles ? 4u : 0u; // 1 listed, 2 covered, 4 listing (the host's switch lags a few frames: same rule here), 8 leave
+            if (slot < hot_ord_cap) {
+                if (slot >= n_eff) {
+                    d_flags |= 8u;
+                } else {
+                    const uint32_t p = (hot_flags & 8u) ? slot : ord_rank_of_slot(slot, n_eff, blockIdx.x - slot); // 8: A/B switch, positions in list order
+                    const uint32_t rank = p < 2u * oh.n_heavy ? p >> 1 : p - oh.n_heavy;
+                    d_half = p < 2u * oh.n_heavy ? 1u + (p & 1u) : 0u;
+                    uint32_t k, idx;
+                    ord_locate(oh, rank, k, idx);
+                    d_tile = ord_rd[RT_ORD_HDR + (1u + k) * hot_n_tiles + idx];
+                    d_flags |= (d_tile >= hot_n_tiles || ord_last_position(oh, rank) >= n_eff) ? 8u : 1u; // (>= n_tiles: never true for lists this kernel wrote;
+                                                             // a pair cut in two by the end of the slots: the tile's index slot renders all of it)
+                }
+            } else {
+                d_tile = idx_tile;
+                // A tile without hits writes nothing, so its word may be left over from an older frame of this generation:
+                // the word is only a hint where to look, and the tile counts as covered iff that list entry really names it.
+                const uint32_t cls = w & 31u, pos = w >> 5;
+                if (tstate == ST_TIMEOUT && cls >= 1u && cls <= ORD_CLASSES && pos < hot_n_tiles) { // (NONEMPTY: its classifier already found it uncovered)
+                    const uint32_t k = cls - 1u;
+                    uint32_t count = 0;
+#pragma unroll
+                    for (uint32_t c = 0; c < ORD_CLASSES; c++) count = c == k ? oh.cnt[c] : count;
+                    if (pos < count && ord_last_position(oh, ord_first(oh, k) + pos) < n_eff && ord_rd[RT_ORD_HDR + (1u + k) * hot_n_tiles + pos] == d_tile) d_flags |= 2u;
+                }
+            }
+            if (lane == 0) { s_decode[0] = d_tile; s_decode[1] = d_flags; s_decode[2] = oh.cost_max; s_half[0] = d_half; }
         }
+        lds_barrier();
+        tile = (uint32_t) __builtin_amdgcn_readfirstlane((int) s_decode[0]);
+        const uint32_t d_flags = (uint32_t) __builtin_amdgcn_readfirstlane((int) s_decode[1]);
+        cost_scale = (uint32_t) __builtin_amdgcn_readfirstlane((int) s_decode[2]);
+        if (d_flags & 8u) return; // workgroup-uniform: a list slot beyond the listed tiles
+        listed = (d_flags & 1u) != 0u;
+        covered = (d_flags & 2u) != 0u;
+        listing = (d_flags & 4u) != 0u;
+        half = (uint32_t) __builtin_amdgcn_readfirstlane((int) s_half[0]);
     }
 #ifdef RT_WF_DEBUG_EXITS
     if ((hot_flags & 0x200u) && !listed) { // timing experiment: index slots leave after the order-state / tile-state loads have come back
@@ -983,7 +1027,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         // pixel of this lane: each wave covers an 8 x 8 quadrant of the tile (tile_px / tile_py)
         const uint32_t tile_x = tile % fa.tiles_x, tile_y = tile / fa.tiles_x;
         const uint32_t x = tile_x * RT_TILE + tile_px(tid), lr = tile_y * RT_TILE + tile_py(tid);
-        const bool inside = x < fa.width && lr < fa.local_rows;
+        const bool inside = x < fa.width && lr < fa.local_rows && (half == 0u || (tid >> 7) + 1u == half); // (tile_py: threads 0-127 are rows 0-7)
         // lanes outside the image trace a clamped pixel (keeps the wave's primary cone tight); their result is dropped
         const uint32_t xc = x < fa.width ? x : fa.width - 1, lrc = lr < fa.local_rows ? lr : fa.local_rows - 1;
         const uint32_t y = global_row(fa, lrc);
@@ -1093,6 +1137,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         bool first = true;
         uint32_t ord_cls = 0, ord_pos = 0; // thread 0: this tile's entry in the next frame's launch order
         if (fa.sparse && tid == 0) s_sparse[0] = 0xFFFFFFFFu; // visible after the first barrier of round 0
+        if (!(hot_flags & 2u) && tid == 0) s_half[0] = 0u;    // (with the lists on, wave 0 wrote it with the decode)
         if (tid == 0) s_zero[0] = 0u;
         float cur_ratio = 1.0f;
         uint32_t n_refl = 0;
@@ -1150,7 +1195,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             const uint32_t n_hits = c0 + c1 + c2 + c3;
             if (first && fa.sparse && tid == 0 && n_hits) // sparse output: a tile with hits takes a slot of the message; the slot
                 s_sparse[0] = atomicAdd(reinterpret_cast<uint32_t *>(fb), 1u); // parked in LDS at once (not in a register across the shadow phase); the barriers of this round publish it before the final store
-            if (first && ord_wr && tid == 0 && n_hits) { // the next frame's launch order: round-0 hits in four cost classes
+            if (first && ord_wr && tid == 0 && n_hits && s_half[0] != 2u) { // the next frame's launch order (census: a split tile counts through its upper half)
                 if (((tile * 0x9E3779B1u) >> 28) == 0u) atomicAdd(&ord_wr[16], 1u); // census, also while the ordering is off
             }
             if (first) RT_STAMP_INFO(((unsigned long long) tile << 32) | n_hits);
@@ -1290,10 +1335,13 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             RT_STAMP(6);
             lds_barrier();
             RT_STAMP(7);
-            if (first && listing && tid == 0) {
+            // (of a split tile's two workgroups the first to get here speaks for the tile: whichever half has hits at all keeps it listed)
+            if (first && listing && tid == 0 &&
+                (s_half[0] == 0u || atomicMax(&fa.order_state[3u * (size_t) fa.ord_stride + tile], fa.ord_frame) != fa.ord_frame)) {
                 // cost class 0 (the costliest) .. 15, on the scale of the previous frame's largest cost; one device atomic per tile with hits
-                // (plus one for the scale), their results only needed at the very end of the workgroup
-                const uint32_t cost = s_cost[0];
+                // (plus one for the scale), their results only needed at the very end of the workgroup.  A half tile reports twice its own
+                // cost -- what the whole tile would have cost, or a little more: once split, a tile stays split.
+                const uint32_t cost = s_half[0] ? 2u * s_cost[0] : s_cost[0];
                 const uint32_t q = cost_scale ? (uint32_t) (((unsigned long long) cost * ORD_CLASSES) / ((unsigned long long) cost_scale + 1ull)) : ORD_CLASSES - 1u;
                 ord_cls = ORD_CLASSES - (q < ORD_CLASSES - 1u ? q : ORD_CLASSES - 1u); // class + 1
                 ord_pos = atomicAdd(&ord_wr[ord_cls - 1u], 1u);
@@ -1398,7 +1446,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             } else if (mslot != 0xFFFFFFFFu && tid == 0) {
                 msg[1] = 1u; // more tiles with hits than the message holds
             }
-        } else if (sx_ < fe.width && sy_ < fe.local_rows) {
+        } else if (sx_ < fe.width && sy_ < fe.local_rows && (s_half[0] == 0u || (tid_ >> 7) + 1u == s_half[0])) { // (a half tile: the other rows are another workgroup's)
             const size_t pix = (size_t) sy_ * fe.width + sx_;
             if (fe.rgba8) {
                 uchar4 px;
@@ -1453,10 +1501,45 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
     const bool ordering = fa->order_state && fa->ord_on;
     const unsigned char *hot_us = gs + fa->off_us;
     const uint32_t *hot_ord_rd = ordering ? fa->order_state + (size_t) fa->ord_read * fa->ord_stride : nullptr;
-    uint32_t hot_flags = (fa->all_cullable ? 1u : 0u) | (ordering ? 2u : 0u) | (n_paint ? 4u : 0u) | (fa->ord_plain ? 8u : 0u);
+    uint32_t hot_flags = (fa->all_cullable ? 1u : 0u) | (ordering ? 2u : 0u) | (n_paint ? 4u : 0u) | (fa->ord_plain ? 8u : 0u) |
+                         ((fa->ord_split & 15u) << 4); // bits 4-7: cost classes whose tiles may be rendered as two half tiles
 #ifdef RT_WF_DEBUG_EXITS
     if (const char *dbg = getenv("MI355RT_DEBUG_EXIT")) hot_flags |= (uint32_t) atoi(dbg) << 8;
 #endif
+    if (fa->ord_split && ordering) {
+        // workgroup slots of the whole GPU for this instantiation and LDS size (bits 20-31): tiles are only split into half tiles while
+        // there are slots to spare.  Asked once per (device, instantiation, LDS size) and thread.
+        struct SlotsKey { int dev, sel; size_t lds; uint32_t slots; };
+        static thread_local SlotsKey memo[4] = {{-1, 0, 0, 0}, {-1, 0, 0, 0}, {-1, 0, 0, 0}, {-1, 0, 0, 0}};
+        static thread_local unsigned memo_next = 0;
+        int dev = 0;
+        (void) hipGetDevice(&dev);
+        uint32_t slots = 0;
+        bool found = false;
+        for (const SlotsKey &k : memo)
+            if (k.dev == dev && k.sel == sel && k.lds == lds) { slots = k.slots; found = true; }
+        if (!found) {
+            int per_cu = 0, cus = 0;
+#define RT_OCC(C, M, G, Q) (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wavefront_tile_kernel<C, G, Q, M>, WG, lds)
+            switch (sel) {
+            case 0: RT_OCC(false, false, false, false); break;
+            case 1: RT_OCC(false, false, false, true); break;
+            case 2: RT_OCC(false, false, true, false); break;
+            case 3: RT_OCC(false, false, true, true); break;
+            case 4: RT_OCC(false, true, false, false); break;
+            case 5: RT_OCC(false, true, false, true); break;
+            case 6: RT_OCC(false, true, true, false); break;
+            case 7: RT_OCC(false, true, true, true); break;
+            default: break; // counting builds: no split (they are not timed)
+            }
+#undef RT_OCC
+            (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            const long long total = (long long) (per_cu > 0 ? per_cu : 0) * (cus > 0 ? cus : 0);
+            slots = (uint32_t) (total > 4095 ? 4095 : total);
+            memo[memo_next++ & 3u] = SlotsKey{dev, sel, lds, slots};
+        }
+        hot_flags |= slots << 20;
+    }
     const ColdArgs cold{*fa, gs, glight, fb, counters, camx, camy};
 #define RT_LAUNCH(C, M, G, Q) hipLaunchKernelGGL((wavefront_tile_kernel<C, G, Q, M>), grid, block, lds, stream, hot_us, hot_ord_rd, fa->n_us, fa->ord_cap, fa->n_tiles, hot_flags, n_scan ? fa->tile_state : nullptr, fa->frame_tag, n_scan, cold)
     switch (sel) {

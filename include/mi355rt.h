@@ -75,6 +75,8 @@ typedef struct rt_scene_desc {
 
 #define RT_FLAG_PLAIN_ORDER 64u /* wavefront kernel: the tiles that had hits start in plain descending-cost order instead of the order that
                                   balances the CUs' loads (rt_wavefront.hip, ord_rank_of_slot); same results, for A/B runs */
+#define RT_FLAG_NOSPLIT 128u   /* wavefront kernel: every tile is rendered by one workgroup (default: the costliest tiles of the previous frame
+                               * by two, one per half tile) -- for A/B */
 
 /* rt_config.format -- framebuffer pixel format */
 #define RT_FMT_RGBA32F 0u     /* 4 x float per pixel, alpha 1.0: the un-quantised colours the CPU back end

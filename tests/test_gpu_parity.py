@@ -417,6 +417,41 @@ def test_box_stage_culling_on_sphere_rows(pkg, oracle, seed):
     assert d["cull_by_kind"]["shadow_directional"] > 0
 
 
+@pytest.mark.parametrize("pose", [-1, 5, 6, 16])
+def test_half_tiles_do_not_change_the_frame(pkg, oracle, pose):
+    """The costliest tiles of the previous frame are rendered by two workgroups, rows 0-7 and rows 8-15 (rt_wavefront.hip, "half
+    tiles"), while the GPU has workgroup slots to spare -- which at these sizes it always has.  Frames with and without
+    (RT_FLAG_NOSPLIT) must be identical, frame after frame, and equal the oracle's."""
+    w, h = 640, 360
+    cam = None if pose < 0 else _orbit_pose(pkg, pose)
+    sc = pkg.Scene.load_from_file(scene_path("20spheres")).set_size(w, h)
+    want = oracle.load_scene(scene_path("20spheres")).with_size(w, h).render(cam=cam, nthreads=8)
+    ra, rb = pkg.Renderer(sc, device=0), pkg.Renderer(sc, device=0, flags=pkg.RT_FLAG_NOSPLIT)
+    for frame in range(6):   # the split starts with the second frame (it needs the first one's costs) and feeds back into the third ...
+        ra.update(cam)
+        rb.update(cam)
+        a, b = ra.download(), rb.download()
+        assert np.array_equal(a, b), frame
+        assert np.array_equal(a[..., :3], want), frame
+    ra.cleanup_update()
+    rb.cleanup_update()
+
+
+@pytest.mark.parametrize("name,depth", [("reflection_test", 4), ("quadratic", None), ("clebsch", None)])
+def test_half_tiles_on_the_other_surface_classes(pkg, name, depth):
+    """Mirrors, general quadrics, the cubic: the same frames with and without half tiles."""
+    sc = pkg.Scene.load_from_file(scene_path(name)).set_size(512, 288)
+    if depth is not None:
+        sc.set_max_reflections(depth)
+    ra, rb = pkg.Renderer(sc, device=0), pkg.Renderer(sc, device=0, flags=pkg.RT_FLAG_NOSPLIT)
+    for frame in range(5):
+        ra.update()
+        rb.update()
+        assert np.array_equal(ra.download(), rb.download()), frame
+    ra.cleanup_update()
+    rb.cleanup_update()
+
+
 def mixed_scene(pkg, seed, w=128, h=96):
     """Random mix of every degree <= 2 class: spheres, ellipsoids / hyperboloids / paraboloids with cross terms, planes;
     directional and point lights; some mirrors."""

@@ -444,8 +444,13 @@ class FramePath:
         kernel ms from HIP events on the render stream inside the timed region)."""
         torch, dist = self.torch, self.dist
         self.overflow_frames = []
+        for _ in range(self.env["args"].settle if not self.dist_on else 0):   # (see --settle)
+            self.step()
+            self.stream.synchronize()
         for _ in range(warmup):
             self.step()
+            if not self.dist_on:   # untimed: let the host see each warm-up frame's feedback words before it sizes the next launch, so that a
+                self.stream.synchronize()   # handful of warm-up frames is enough for the launch order to settle (it lags by the queue depth otherwise)
         self.flush()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.record_kernel_events = self.dist_on   # N = 1: the timed region is K back-to-back launches, one event pair suffices
@@ -772,6 +777,7 @@ def main():
     ap.add_argument("--no-alt", action="store_true")
     ap.add_argument("--no-orbit", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="N = 1: time K plain launches instead of one hipGraph of them")
+    ap.add_argument("--settle", type=int, default=0, help="N = 1: untimed frames in front of the --warmup steps (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     args = ap.parse_args()

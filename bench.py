@@ -9,11 +9,16 @@ Lambert shading and the mirror-bounce loop, written to a framebuffer resident in
 Metric (BASELINE.json): Mrays/s on scenes/20spheres.yml; a ray = one primary, shadow or reflection ray
 (SURVEY.md 8(d)); rays per frame are counted by the kernel itself (RT_FLAG_COUNT pass before timing).
 
-N = 1: BASELINE config 2, 20spheres @ 1920x1080, camera = identity (the reference host's start-up pose), RGBA32F.
-N > 1: weak scaling -- the same scene at N x the pixels (same 16:9 aspect), rows band-cyclic over the ranks
-(no data-path communication while rendering), one RCCL gather to rank 0 per frame + a device reassembly kernel on
-rank 0, as BASELINE.json's north_star prescribes.  The headline `value` is measured on the SAME output as N = 1
-(RGBA32F, dense rows); the RGBA8 / sparse-tile transport is timed in a second region and reported as `config.alt`.
+N = 1: BASELINE config 2, 20spheres @ 1920x1080, camera = identity (the reference host's start-up pose), RGBA32F; the line
+also carries a `configs` array with all five BASELINE configs on this GPU (short regions) and `single_frame_ms`, what update()
+returns for one synchronised frame (src/update-cuda.cu:178-189).
+N > 1: BASELINE config 5, 20spheres @ 7680x4320 -- the configuration BASELINE.json names for several GPUs -- rows band-cyclic
+over the N ranks (no data-path communication while rendering), one RCCL gather to rank 0 per frame + a device reassembly
+kernel on rank 0, as BASELINE.json's north_star prescribes: total work is fixed ("scaling": "strong").  Rank 0 first renders
+the whole 8K frame alone, so that the line carries its own denominator (`speedup_vs_1gpu_config5`), and the ranks measure the
+link bandwidth into rank 0 (`gather_bound_ms`).  The headline `value` is measured on the SAME output as N = 1 (RGBA32F, dense
+rows); the RGBA8 / sparse-tile transport is timed in a second region and reported as `config.alt`.  (--workload config2w keeps
+the weak-scaled 1080p workload of rounds 1-2.)
 
 Prints ONE JSON line (rank 0).  The oracle (oracle/) is used ONLY for the `cpu_baseline` legs.
 """
@@ -34,8 +39,10 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 FP64 lanes/clk x
                                  # peak (157.3 TF, MI355X_MICROARCH.md chip table); checked by profiles/*fp64_peak*
 HBM_PEAK_GBS = 8000.0
 DIV_FLOPS_IN_ISA, SQRT_FLOPS_IN_ISA = 12.0, 14.0   # FP64 instruction-flops of hipcc's expansion of one division / square root (see roofline.table_in_pmc_terms)
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.txt")
-KERNEL_STATS = "profiles/r02_final_kernel_stats.csv"
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.txt")
+KERNEL_STATS = "profiles/r03_kernel_stats.json"   # tools/kernel_stats_summarize.py: rocprofv3 --kernel-trace --stats of this command, stamped with the kernel sources' digest
+CONFIGS = {"config1": ("quadratic", 640, 480, None), "config2": ("20spheres", 1920, 1080, None), "config3": ("reflection_test", 1920, 1080, 4),
+           "config4": ("clebsch", 3840, 2160, None), "config5": ("20spheres", 7680, 4320, None)}
 KERNEL_SOURCES = ["cuda-ray-tracer_amd/csrc/rt_wavefront.hip", "cuda-ray-tracer_amd/csrc/rt_math.hpp",
                   "cuda-ray-tracer_amd/csrc/rt_scene_dev.h", "cuda-ray-tracer_amd/csrc/rt_wavefront_math.hpp"]
 
@@ -76,19 +83,19 @@ def spawn_ranks(n):
 # ----------------------------------------------------------------------------------------------------------------
 # workloads
 # ----------------------------------------------------------------------------------------------------------------
-def workload_for(n_gpus, name):
-    if name == "config5":
-        return "20spheres", 7680, 4320, None
-    if name == "config3":
-        return "reflection_test", 1920, 1080, 4
-    if name == "config4":
-        return "clebsch", 3840, 2160, None
-    if name == "config1":
-        return "quadratic", 640, 480, None
+def workload_for(n_gpus, name, dist_on=False):
+    """auto: BASELINE config 2 on one GPU, BASELINE config 5 (the 8K frame) as soon as the frame is distributed.  config2w: the
+    weak-scaled 1080p frame (N x the pixels) of rounds 1-2."""
+    if name == "auto":
+        name = "config5" if (n_gpus > 1 or dist_on) else "config2"
+    if name in CONFIGS:
+        return (name,) + CONFIGS[name]
+    if name != "config2w":
+        raise SystemExit(f"bench.py: unknown --workload {name}")
     s = math.sqrt(n_gpus)
     w = int(round(1920 * s / 16.0)) * 16
     h = int(round(w * 9 / 16.0))
-    return "20spheres", w, h, None
+    return "config2w", "20spheres", w, h, None
 
 
 def orbit_pose(pkg, i, n=24):
@@ -182,18 +189,17 @@ def kernel_source_digest():
 
 def rocprof_kernel_avg_ms(args, world):
     """Average duration of the product kernel in the committed rocprofv3 --kernel-trace --stats summary of this command (same
-    workload only); None when the file is missing.  Reported next to this run's own HIP-event figure, never instead of it."""
-    if world != 1 or args.workload != "config2" or args.kernel != "wavefront" or args.mode != "strict" or args.format != "rgba32f" or args.camera != "static":
+    workload only), and whether the summary still belongs to the kernel sources; None when the file is missing.  Reported next
+    to this run's own HIP-event figure, never instead of it."""
+    if world != 1 or args.workload_name != "config2" or args.kernel != "wavefront" or args.mode != "strict" or args.format != "rgba32f" or args.camera != "static":
         return None
     try:
-        import csv
         with open(os.path.join(ROOT, KERNEL_STATS)) as f:
-            for row in csv.DictReader(f):
-                if "wavefront_tile_kernel<false" in row["Name"]:
-                    return float(row["AverageNs"]) * 1e-6
+            st = json.load(f)
+        return {"avg_ms": float(st["average_ns"]) * 1e-6, "stale": st.get("kernel_source_digest") != kernel_source_digest(), "kernel": st.get("kernel"),
+                "launches": st.get("calls")}
     except Exception:
-        pass
-    return None
+        return None
 
 
 def pmc_profile(args, world):
@@ -201,7 +207,7 @@ def pmc_profile(args, world):
     tools/pmc_profile.sh; FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled as the MI355X guide prescribes for gfx950).
     NOT measured by this run: the source is named in the JSON line, and the figures are dropped when the kernel sources
     have changed since the passes were taken or when this is not the workload they were taken on."""
-    if world != 1 or args.workload != "config2" or args.kernel != "wavefront" or args.mode != "strict" or args.format != "rgba32f" or args.camera != "static":
+    if world != 1 or args.workload_name != "config2" or args.kernel != "wavefront" or args.mode != "strict" or args.format != "rgba32f" or args.camera != "static":
         return None
     path = os.path.join(ROOT, PMC_SUMMARY)
     try:
@@ -522,6 +528,124 @@ class FramePath:
         self.ren.cleanup_update()
 
 
+
+# ----------------------------------------------------------------------------------------------------------------
+# N = 1: every BASELINE config on this GPU (short regions), and what update() returns for one frame
+# ----------------------------------------------------------------------------------------------------------------
+def counters_of(pkg, scene, device, flags, cam=None):
+    rc = pkg.Renderer(scene, device=device, flags=flags | pkg.RT_FLAG_COUNT)
+    rc.update(cam)
+    d = rc.counters_detail()
+    rc.cleanup_update()
+    return d
+
+
+def measure_config(pkg, graft, name, device, flags, table, frames, check_rows):
+    """One BASELINE config on one GPU: `frames` frames issued back to back on one stream (plain launches, one HIP event pair
+    around them, after three synchronised warm-up frames), the median of synchronised single frames (`single_frame_ms`: what
+    the reference's update() returns, src/update-cuda.cu:178-189), the roofline fraction from this config's own work counters,
+    and -- part of the cpu_baseline leg, skipped with it -- a sample of rows compared with the oracle."""
+    import numpy as np
+    import torch
+    scene_name, W, H, max_refl = CONFIGS[name]
+    path = os.path.join(ROOT, "scenes", scene_name + ".yml")
+    scene = pkg.Scene.load_from_file(path).set_size(W, H)
+    if max_refl is not None:
+        scene.set_max_reflections(max_refl)
+    cnt = counters_of(pkg, scene, device, flags)
+    arr = scene.arrays()
+    flops, _, _ = algorithmic_flops(cnt, table, arr)
+    dense = dense_reference_flops(cnt, table)
+    capped = flops > dense
+    flops = min(flops, dense)
+    r = pkg.Renderer(scene, device=device, flags=flags)
+    stream = torch.cuda.current_stream()
+    singles = [r.update(stream=stream.cuda_stream) for _ in range(3 + max(5, min(20, frames)))][3:]   # (the first three: warm-up, launch order settles)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(frames):
+        r.update(stream=stream.cuda_stream, timed=False)
+    e1.record(stream)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / frames
+    rays = cnt["primary_rays"] + cnt["shadow_rays"] + cnt["reflect_rays"]
+    out = {"config": name, "workload": f"{scene_name}.yml {W}x{H}" + (f", max_reflections {max_refl}" if max_refl is not None else "") + ", camera identity, RGBA32F",
+           "frames": frames, "ms_per_step": ms, "single_frame_ms": float(np.median(singles)), "frames_per_s": 1e3 / ms, "value": rays / ms / 1e3, "unit": "Mrays/s",
+           "rays_per_frame": int(rays), "tests_per_frame": int(cnt["tests"]),
+           "roofline": {"bound": "valu", "achieved": flops / (ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops,
+                        "capped_at_dense_reference_count": capped, "dense_reference_flops_per_launch": dense,
+                        "hbm_write_gbs": float(W) * H * 16.0 / (ms * 1e-3) / 1e9}}
+    if check_rows:
+        O = graft.load_oracle()
+        img = r.download()
+        rows = np.arange(0, H, max(1, H // 24), dtype=np.uint32)
+        want = O.load_scene(path).with_size(W, H, max_refl).render(rows=rows, nthreads=min(16, os.cpu_count() or 1))
+        got = img[rows][..., :3]
+        diff = np.abs(got.astype(np.float64) - want)
+        rel = diff / np.maximum(np.maximum(np.abs(got), np.abs(want)), 1e-300)
+        out["oracle_row_sample"] = {"rows": int(rows.size), "identical": bool(np.array_equal(got, want)),
+                                    "pixels_over_1e-5": int(((rel > 1e-5) & (diff > 1e-7)).any(axis=-1).sum()), "pixels": int(rows.size * W)}
+    r.cleanup_update()
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# N > 1: the 1-GPU denominator of the same frame, and the bandwidth of the links into rank 0
+# ----------------------------------------------------------------------------------------------------------------
+def one_gpu_frame_ms(pkg, scene, device, flags, cam, fmt, frames=5):
+    """Rank 0 alone renders the WHOLE frame of the distributed workload (no sharding, no transport): frames issued back to back
+    after three synchronised warm-up frames."""
+    import torch
+    r = pkg.Renderer(scene, device=device, flags=flags, fmt=fmt)
+    stream = torch.cuda.current_stream()
+    for _ in range(3):
+        r.update(cam, stream=stream.cuda_stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(frames):
+        r.update(cam, stream=stream.cuda_stream, timed=False)
+    e1.record(stream)
+    e1.synchronize()
+    r.cleanup_update()
+    torch.cuda.empty_cache()
+    return e0.elapsed_time(e1) / frames
+
+
+def link_bandwidth(dist, torch, rank, world, dev, cdev, nccl, mbytes=64):
+    """GB/s into rank 0: one `mbytes` message per peer, one peer at a time (`per_peer_gbs`), then all peers at once through the
+    very collective the frames use (`gather_ingest_gbs`, bytes arriving at rank 0 / time)."""
+    n = mbytes << 20
+    buf = torch.empty(n, dtype=torch.uint8, device=cdev)
+    per_peer = []
+    if world > 1:
+        for peer in range(1, world):
+            for it in range(2):   # the first transfer opens the connection
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                if rank == peer:
+                    dist.send(buf, dst=0)
+                elif rank == 0:
+                    dist.recv(buf, src=peer)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            per_peer.append(n / dt / 1e9)   # rank 0's clock is the one reported
+    recv = [torch.empty(n, dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None
+    for it in range(2):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.gather(buf, recv, dst=0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    ingest = n * max(1, world - 1) / dt / 1e9
+    del recv, buf
+    torch.cuda.empty_cache()
+    return {"message_mbytes": mbytes, "per_peer_gbs": per_peer, "gather_ingest_gbs": ingest,
+            "what": "per_peer: dist.send / recv of one message, one peer at a time; gather_ingest: dist.gather of one message per rank, bytes from the other ranks "
+                    "arriving at rank 0 / wall time (world 1: the self copy)"}
+
 # ----------------------------------------------------------------------------------------------------------------
 def run_rank(args, world):
     import numpy as np
@@ -554,7 +678,7 @@ def run_rank(args, world):
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collectives' tensors live
 
     pkg = graft.load_package()
-    scene_name, W, H, max_refl = workload_for(world, args.workload)
+    args.workload_name, scene_name, W, H, max_refl = workload_for(world, args.workload, dist_on)
     scene = pkg.Scene.load_from_file(os.path.join(ROOT, "scenes", scene_name + ".yml")).set_size(W, H)
     if max_refl is not None:
         scene.set_max_reflections(max_refl)
@@ -567,6 +691,16 @@ def run_rank(args, world):
     n_orbit = 24
     cams = [orbit_pose(pkg, i, n_orbit) for i in range(n_orbit)] if args.camera == "orbit" else [pkg.IDENTITY]
     env = dict(pkg=pkg, args=args, world=world, rank=rank, local_rank=local_rank, dev=dev, cdev=cdev, W=W, H=H, scene=scene, flags=flags, dist_on=dist_on)
+
+    # ---- N > 1: rank 0 renders the whole frame alone (the denominator of the speed-up), then the links into rank 0 are measured ----
+    one_gpu = links = None
+    if dist_on and not args.no_one_gpu:
+        if rank == 0:
+            one_gpu = {"rgba32f_ms": one_gpu_frame_ms(pkg, scene, local_rank, flags, cams[0], pkg.RT_FMT_RGBA32F),
+                       "rgba8_ms": one_gpu_frame_ms(pkg, scene, local_rank, flags, cams[0], pkg.RT_FMT_RGBA8),
+                       "what": f"rank 0 alone, the whole {W}x{H} frame in one context, 5 frames issued back to back after 3 synchronised warm-up frames"}
+        dist.barrier()
+        links = link_bandwidth(dist, torch, rank, world, dev, cdev, args.backend == "nccl")
 
     # ---- ray / work accounting: one counting frame per camera pose (not timed) ----
     keys = ["primary_rays", "shadow_rays", "reflect_rays", "tests", "hits", "solves", "tests_executed", "cull_evals"]
@@ -621,7 +755,7 @@ def run_rank(args, world):
 
     # ---- N = 1, static camera: the same kernel over an orbit of 24 poses (frame time depends on the view) ----
     orbit = None
-    if not dist_on and args.camera == "static" and args.workload == "config2" and not args.no_orbit:
+    if not dist_on and args.camera == "static" and args.workload_name == "config2" and not args.no_orbit:
         ts = []
         for i in range(n_orbit):
             cam = orbit_pose(pkg, i, n_orbit)
@@ -674,11 +808,12 @@ def run_rank(args, world):
                 "time_vs_dense_algorithm_at_100pct_fp64_peak": (dense_frame / (FP64_VECTOR_PEAK_TFLOPS * 1e12 * world)) / step_s,
                 "hbm_write_gbs": fb_bytes / (kernel_ms * 1e-3) / 1e9, "hbm_frac": fb_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         rp = rocprof_kernel_avg_ms(args, world)
-        if rp is not None:
-            roof["kernel_ms_what"] = ("time per launch of launches issued back to back (kernel + the ~2.5-3 us the command processor needs between two dependent launches, "
-                                      "profiles/r02_launch_overheads.txt): the conservative denominator")
-            roof["rocprof_kernel_avg_ms"] = rp
-            roof["rocprof_kernel_avg_source"] = f"{KERNEL_STATS} (rocprofv3 --kernel-trace --stats of this command, committed; begin-to-end of the kernel alone)"
+        if rp is not None and not rp["stale"]:
+            roof["rocprof_kernel_avg_ms"] = rp["avg_ms"]
+            roof["rocprof_kernel_avg_source"] = (f"{KERNEL_STATS} (rocprofv3 --kernel-trace --stats of this command, committed, {rp['launches']} launches of {rp['kernel']}; "
+                                                 "begin-to-end of the kernel alone; taken with the kernel sources this run was built from)")
+        elif rp is not None:
+            roof["rocprof_kernel_avg_source"] = f"{KERNEL_STATS} is older than the kernel sources: dropped"
         if pmc and "flops" in pmc:
             roof["pmc_flops_per_launch"] = pmc["flops"]
             roof["pmc_flops_formula"] = "(SQ_INSTS_VALU_ADD_F64 + SQ_INSTS_VALU_MUL_F64 + 2 x SQ_INSTS_VALU_FMA_F64) x 64 x active-lane fraction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 64)"
@@ -700,12 +835,14 @@ def run_rank(args, world):
             roof["valu_busy"], roof["valu_busy_formula"] = pmc["valu_busy"], pmc["valu_busy_formula"]
         cam_txt = "camera identity" if args.camera == "static" else f"camera moving along an orbit of {n_orbit} poses (a new pose every frame)"
         result = {
-            "metric": "Mrays/sec, 20spheres.yml @1920x1080 (weak-scaled with --gpus)" if args.workload == "config2" else f"Mrays/sec, {args.workload}",
+            "metric": {"config2": "Mrays/sec, 20spheres.yml @1920x1080", "config5": "Mrays/sec, 20spheres.yml @7680x4320 (BASELINE config 5), rows over the ranks",
+                       "config2w": "Mrays/sec, 20spheres.yml @1920x1080 x N pixels (weak-scaled)"}.get(args.workload_name, f"Mrays/sec, {args.workload_name}"),
             "value": rays_timed / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "frames_per_s": args.steps / dt,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if (args.workload_name == "config2w" or not dist_on) else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "rccl_ranks": dist.get_world_size() if (dist_on and args.backend == "nccl") else 0,
-            "config": {"workload": f"{scene_name}.yml {W}x{H}, {cam_txt}, {args.format.upper()} framebuffer", "objects": int(arr["coefs"].shape[0]),
+            "config": {"workload": f"BASELINE {args.workload_name}: {scene_name}.yml {W}x{H}, {cam_txt}, {args.format.upper()} framebuffer" + (f", rows in bands of {args.band_rows} over {world} rank(s)" if dist_on else ""),
+                       "objects": int(arr["coefs"].shape[0]),
                        "lights": int(arr["light_p"].shape[0]), "rays_per_frame": int(rays_per_pose[0]) if len(cams) == 1 else float(np.mean(rays_per_pose)),
                        "tests_per_frame": total0["tests"], "kernel_mode": args.mode, "kernel": args.kernel, "framebuffer_format": args.format,
                        "parallelism": f"rows band-cyclic x{world} (band {args.band_rows}), {args.backend} gather to rank 0 + device reassembly" if dist_on else "single GPU"},
@@ -719,6 +856,39 @@ def run_rank(args, world):
             result["config"]["gather"] = gather_main
         if alt:
             result["config"]["alt"] = alt
+        if os.environ.get("MI355RT_LIB"):
+            result["config"]["MI355RT_LIB"] = os.environ["MI355RT_LIB"]   # (another build of the library was measured, not the in-tree product)
+        if dist_on and one_gpu:
+            # ---- the contract of BASELINE config 5: how much faster than ONE GPU rendering the same frame? ----
+            result["one_gpu_same_frame"] = one_gpu
+            result["speedup_vs_1gpu_" + args.workload_name] = {"rgba32f_dense": one_gpu["rgba32f_ms"] / (step_s * 1e3),
+                                                                "rgba8_sparse" if (alt and alt["gather"]["kind"] == "sparse tiles") else "rgba8": (one_gpu["rgba8_ms"] / alt["ms_per_step"]) if alt else None,
+                                                                "what": "time of one GPU rendering the whole frame / time per step of the N ranks incl. gather and reassembly; target of BASELINE.json: >= 3.5 at N = 8"}
+            bw = links["gather_ingest_gbs"] if links else None
+            into_root = float(gather_main["bytes_per_rank"]) * max(0, world - 1)
+            result["links_into_rank0"] = links
+            result["gather_bound_ms"] = {"rgba32f_dense": into_root / (bw * 1e9) * 1e3 if bw else None,
+                                         "rgba8_alt": (float(alt["gather"]["bytes_per_rank"]) * max(0, world - 1) / (bw * 1e9) * 1e3) if (alt and bw) else None,
+                                         "bytes_into_rank0_rgba32f_dense": into_root,
+                                         "what": "bytes arriving at rank 0 per frame / the ingest bandwidth measured above (world 1: nothing arrives, 0): the step cannot be shorter"}
+            # DESIGN.md section 7's expectation, written down before the 8-GPU run: the render shrinks with N, the gather does not
+            pred = {}
+            for n in (2, 4, 8):
+                per_rank = float(W) * H * 16.0 / n
+                for gbs in (50.0, 75.0):
+                    g_ms = per_rank / (gbs * 1e9) * 1e3   # the N-1 senders use distinct links: the slowest one bounds the gather
+                    pred[f"n{n}_link{int(gbs)}GBs"] = {"render_ms": one_gpu["rgba32f_ms"] / n, "gather_ms": g_ms, "step_ms": max(one_gpu["rgba32f_ms"] / n, g_ms),
+                                                      "speedup": one_gpu["rgba32f_ms"] / max(one_gpu["rgba32f_ms"] / n, g_ms)}
+            result["predicted_rgba32f_dense"] = {"table": pred, "what": "step = max(render / N, one rank's rows over one xGMI link at 50 / 75 GB/s), pipelined over two buffer sets (DESIGN.md section 7): "
+                                                 "the RGBA32F frame is bound by the gather as soon as N > 1; only the RGBA8 sparse transport (config.alt) can follow the kernel"}
+        if not dist_on and args.workload_name == "config2" and args.kernel == "wavefront" and args.camera == "static" and not args.no_configs:
+            # ---- all five BASELINE configs on this GPU + what update() returns for one frame ----
+            result["configs"] = []
+            for name in ("config1", "config2", "config3", "config4", "config5"):
+                result["configs"].append(measure_config(pkg, graft, name, local_rank, flags, table, 5 if name == "config5" else 20, not args.no_cpu_baseline))
+            result["single_frame_ms"] = result["configs"][1]["single_frame_ms"]
+            result["single_frame_ms_what"] = ("median of 20 synchronised single frames of the headline workload, one HIP event pair around each launch: what update() returns "
+                                              "(src/update-cuda.cu:178-189); the headline's ms_per_step is per frame of frames issued back to back")
         if not args.no_cpu_baseline and world == 1:
             O = graft.load_oracle()
             osc = O.load_scene(os.path.join(ROOT, "scenes", scene_name + ".yml")).with_size(W, H, max_refl)
@@ -754,7 +924,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="config2", help="config2 (default, weak-scaled with --gpus) | config1 | config3 | config4 | config5")
+    ap.add_argument("--workload", default="auto", help="auto (default): BASELINE config2 on one GPU, BASELINE config5 (the 8K frame, rows over the ranks) with N > 1 | "
+                                                       "config1 .. config5 | config2w (1080p x N pixels, the weak-scaled workload of rounds 1-2)")
     ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "wavefront-nocull", "simple"],
                     help="A/B switch; the product default is the culling wavefront kernel")
@@ -776,6 +947,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="N = 1: run the N > 1 code path (process group, gather, reassembly) with one rank")
     ap.add_argument("--no-alt", action="store_true")
     ap.add_argument("--no-orbit", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the `configs` array (all five BASELINE configs, short regions)")
+    ap.add_argument("--no-one-gpu", action="store_true", help="N > 1: skip rank 0's single-GPU render of the whole frame and the link measurement")
     ap.add_argument("--no-graph", action="store_true", help="N = 1: time K plain launches instead of one hipGraph of them")
     ap.add_argument("--settle", type=int, default=0, help="N = 1: untimed frames in front of the --warmup steps (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

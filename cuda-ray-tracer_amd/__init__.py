@@ -22,6 +22,7 @@ MULTI_LIB_PATH = os.path.join(_HERE, "libmi355rt_multi.so")   # several GPUs beh
 RT_NCOEF = 20
 RT_FLAG_STRICT, RT_FLAG_FAST, RT_FLAG_COUNT, RT_FLAG_SIMPLE, RT_FLAG_NOCULL, RT_FLAG_STATIC_ORDER, RT_FLAG_NOSCAN, RT_FLAG_PLAIN_ORDER = 0, 1, 2, 4, 8, 16, 32, 64
 RT_FLAG_NOSPLIT = 128
+RT_FLAG_NOLEAN = 256
 RT_FMT_RGBA32F, RT_FMT_RGBA8 = 0, 1
 RT_ERR_NO_DEVICE = -4
 

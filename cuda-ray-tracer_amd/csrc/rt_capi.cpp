@@ -25,7 +25,7 @@ extern "C" hipError_t rt_launch_trace_fast(const FrameArgs *, const DevObject *,
 extern "C" hipError_t rt_launch_wavefront_strict(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, const double *, const double *, hipStream_t);
 extern "C" hipError_t rt_launch_wavefront_fast(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, const double *, const double *, hipStream_t);
 
-extern "C" size_t rt_wavefront_lds_bytes_strict(uint32_t, uint32_t, int, uint32_t);
+extern "C" size_t rt_wavefront_lds_bytes_strict(uint32_t, uint32_t, int, uint32_t, int);
 extern "C" hipError_t rt_launch_assemble_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" hipError_t rt_launch_pack_sparse_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t rt_launch_assemble_sparse_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, void *, uint32_t, uint32_t, hipStream_t);
@@ -102,15 +102,17 @@ struct rt_ctx {
     hipEvent_t ev_done = nullptr;      // recorded behind every render: a render on ANOTHER stream waits for it (frames of a context are ordered)
     hipStream_t last_stream = nullptr;
     bool rendered = false;
+    bool captured = false;      // the last render was recorded into a stream capture: ev_done was not (an event recorded inside a capture orders nothing outside it)
     bool counted = false;
     bool zero_counters = false; // diagnostic builds: clear counters[] before every render
     uint64_t *d_stamps = nullptr;
     double *d_camx = nullptr, *d_camy = nullptr; // per-column / per-row camera-plane coordinates
     size_t n_stamp_rows = 0;
-    uint32_t frame = 0; // renders so far: selects the launch-order generation (FrameArgs::order_state)
+    uint64_t frame = 0; // renders so far: selects the launch-order generation (FrameArgs::order_state); 64 bits: frame % 3 must never skip
     uint32_t tag = 0;   // frame tag of the scan workgroups' tile words (FrameArgs::tile_state); unique per render, never 0
     uint32_t *h_listed = nullptr; // host-mapped words the kernel writes (FrameArgs::ord_host)
     uint32_t ord_split = 0;       // FrameArgs::ord_split of non-sparse frames
+    bool lean_ok = false;         // the scene qualifies for the wave-per-block instantiation (FrameArgs::lean; dense frames only)
     bool ord_on = true;           // launch-order feedback in use (off while most tiles have hits)
 };
 
@@ -430,6 +432,22 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
             e.r = o.bs_radius;
             e.inv_r = (o.bs_radius < INFINITY) ? 1.0 / o.bs_radius : 0.0;
             e.orig = i;
+            // window of the reference's own t0 inside which a shadow ray leaving this sphere towards a directional light in front of the
+            // surface cannot be blocked by this sphere (rt_wavefront.hip, own_sphere_skippable): (1e-10 (r^2 + 1) + 1e-20 S^2, (r + 1)^2),
+            // S = 2 |centre|_1 + 3 r + 3; rounded inwards to FP32.  No window (+inf, 0) for spheres without a real radius.
+            e.own_lo = INFINITY;
+            e.own_hi = 0.0f;
+            if (o.bs_radius < INFINITY && o.bs_radius > 0.0) {
+                const double r = o.bs_radius, S = 2.0 * (std::fabs(o.bs_center[0]) + std::fabs(o.bs_center[1]) + std::fabs(o.bs_center[2])) + 3.0 * r + 3.0;
+                const double lo = 1e-10 * (r * r + 1.0) + 1e-20 * S * S, hi = (r + 1.0) * (r + 1.0);
+                float flo = (float) lo, fhi = (float) hi;
+                if (!((double) flo > lo)) flo = std::nextafterf(flo, INFINITY);
+                if (!((double) fhi < hi)) fhi = std::nextafterf(fhi, -INFINITY);
+                if (std::isfinite(lo) && std::isfinite(hi) && (double) flo > lo && (double) fhi < hi && flo < fhi) {
+                    e.own_lo = flo;
+                    e.own_hi = fhi;
+                }
+            }
             t_us.push_back(e);
         } else if (o.cls & (RT_CLS_SQUARE | RT_CLS_CROSS)) {
             GqEntry e{};
@@ -496,9 +514,14 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
         l.backface_exact = (!l.spherical && finite) ? 1u : 0u;
     }
 
-    if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u) > 160u * 1024u) {
+    // the wave-per-block instantiation: unit spheres only, every one with a bounding radius, no mirror (sparse frames take the other one)
+    ctx->lean_ok = !(cfg.flags & (RT_FLAG_SIMPLE | RT_FLAG_NOLEAN)) && fa.all_cullable && fa.n_us == sd->n_objects && !fa.has_mirror && fa.n_gq == 0 && fa.n_lin == 0 &&
+                   fa.n_cub == 0;
+    if (std::getenv("MI355RT_NOLEAN")) ctx->lean_ok = false; // (experiments)
+    if (ctx->lean_ok) ctx->ord_split = 0u; // its waves are independent: a second workgroup per tile would shorten nothing
+    if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u, 0) > 160u * 1024u) {
         return fail(RT_ERR_SCENE, "rt_create: scene needs %zu bytes of LDS per workgroup (limit 160 KiB)",
-                    rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u));
+                    rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u, 0));
     }
     int rc = RT_OK;
     auto hip_ok = [&](hipError_t err, const char *what) {
@@ -578,6 +601,7 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
     FrameArgs &fa = ctx->fa;
     fa.sparse = sparse ? 1u : 0u;
     fa.sparse_cap = sparse ? sparse_cap : 0u;
+    fa.lean = (ctx->lean_ok && !sparse) ? 1u : 0u;
     std::memcpy(fa.cam, cam, sizeof(double) * 16);
     // g_ray_origin = camera_matrix * (0,0,0,1), src/update-cpu.cpp:123 -- glm order (m0*x + m1*y) + (m2*z + m3*w)
     for (int r = 0; r < 3; r++) fa.origin[r] = (cam[0 + r] * 0.0 + cam[4 + r] * 0.0) + (cam[8 + r] * 0.0 + cam[12 + r] * 1.0);
@@ -608,7 +632,15 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
     // A context's frames depend on each other on the device (launch-order generations: read k, append k + 1, clear k + 2; tile words
     // tagged per frame), so they must run in the order they were issued.  On one stream they do; when the caller switches streams,
     // the new stream first waits for the previous frame.
-    if (ctx->rendered && stream != ctx->last_stream) RT_HIP(hipStreamWaitEvent(stream, ctx->ev_done, 0));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream) RT_HIP(hipStreamIsCapturing(stream, &cap));
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (ctx->rendered && stream != ctx->last_stream) {
+        if (ctx->captured || capturing)
+            return fail(RT_ERR_INVALID, "rt_render: a context whose frames were captured into a graph on one stream must stay on that stream (frames of a context are "
+                                        "ordered on the device, and a capture cannot be ordered against another stream through an event)");
+        RT_HIP(hipStreamWaitEvent(stream, ctx->ev_done, 0));
+    }
     void *fb = dev_fb ? dev_fb : ctx->d_fb;
     if (sparse) RT_HIP(hipMemsetAsync(fb, 0, 16, stream)); // message header: count, overflow
     const int count = (ctx->cfg.flags & RT_FLAG_COUNT) ? 1 : 0;
@@ -633,9 +665,9 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
         fa.n_scan = (fa.n_tiles + RT_SCAN_TILES - 1) / RT_SCAN_TILES;
     }
     if (fa.order_state) { // rotate the launch-order generations: read k, write k+1, clear k+2
-        fa.ord_read = ctx->frame % 3u;
-        fa.ord_write = (ctx->frame + 1u) % 3u;
-        fa.ord_zero = (ctx->frame + 2u) % 3u;
+        fa.ord_read = (uint32_t) (ctx->frame % 3u);
+        fa.ord_write = (uint32_t) ((ctx->frame + 1u) % 3u);
+        fa.ord_zero = (uint32_t) ((ctx->frame + 2u) % 3u);
         // list slots of this launch: what an earlier frame reported (the host runs ahead of the device, so the words
         // are a few frames old) plus a quarter and 64; too few only means that the surplus tiles start in index order.
         // The ordering is switched off while the census says that >= 25 % of the tiles have hits (back on below 20 %).
@@ -654,7 +686,12 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
         fa.ord_cap = cap;
         fa.ord_on = ctx->ord_on ? 1u : 0u;
         fa.ord_split = fa.sparse ? 0u : ctx->ord_split; // (a sparse message has one slot per tile)
-        fa.ord_frame = ctx->frame + 1u;                 // never 0 (the words start out 0); wraps after 2^32 frames
+        // this frame's number for the per-tile "entered by" words of split tiles: 1 .. 0xFFFFFFF0, never 0 (the words start out 0).  The
+        // election is an atomicMax, so when the number starts over (every 2^32 - 16 frames) the words are cleared first -- the same
+        // guard the tile-word tag has above.
+        fa.ord_frame = (uint32_t) (ctx->frame % 0xFFFFFFF0ull) + 1u;
+        if (fa.ord_frame == 1u && ctx->frame != 0u)
+            RT_HIP(hipMemsetAsync(fa.order_state + 3u * (size_t) fa.ord_stride, 0, sizeof(uint32_t) * fa.n_tiles, stream));
         ctx->frame++;
     }
     if (ms) RT_HIP(hipEventRecord(ctx->ev0, stream));
@@ -668,7 +705,8 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
                  : rt_launch_wavefront_strict(&fa, ctx->d_obj, ctx->d_light, fb, ctx->d_counters, count, ctx->d_camx, ctx->d_camy, stream);
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     ctx->counted = count != 0;
-    RT_HIP(hipEventRecord(ctx->ev_done, stream));
+    if (!capturing) RT_HIP(hipEventRecord(ctx->ev_done, stream));
+    ctx->captured = capturing;
     ctx->last_stream = stream;
     ctx->rendered = true;
     if (ms) {

@@ -78,6 +78,8 @@ struct rt_multi {
     void *full = nullptr;              // root device: [height][width] pixels
     hipEvent_t ev_gathered = nullptr, ev_assembled = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool have_assembled = false;
+    void *last_full = nullptr;         // where the last frame went (rt_render_multi's root_full_fb, or `full`): what rt_multi_download reads
+    bool in_flight_failed = false;     // a frame failed after part of it had been enqueued: events and receive slots are in an unknown state
 };
 
 extern "C" int rt_multi_destroy(rt_multi *m)
@@ -219,9 +221,15 @@ extern "C" int rt_create_multi(rt_multi **out, const rt_scene_desc *scene, const
 extern "C" int rt_render_multi(rt_multi *m, const double cam[16], void *root_full_fb, float *ms)
 {
     if (!m || !cam) return fail(RT_ERR_INVALID, "rt_render_multi: null argument");
+    if (m->in_flight_failed) return fail(RT_ERR_DEVICE, "rt_render_multi: an earlier frame of this object failed with part of it enqueued; destroy it and create a new one");
     DeviceRestore restore;
     const uint32_t n = m->n, P = m->parts;
     void *full = root_full_fb ? root_full_fb : m->full;
+    struct FailGuard { // any early return between here and the end leaves sends / receives / events half issued
+        rt_multi *m;
+        bool ok = false;
+        ~FailGuard() { if (!ok) m->in_flight_failed = true; }
+    } guard{m};
     M_HIP(hipSetDevice(m->dev[0]));
     if (ms) M_HIP(hipEventRecord(m->ev_t0, m->s_render[0]));
     if (m->world == 1 && m->transport == DIRECT) { // one device, one part: the frame is this context's rows
@@ -292,6 +300,8 @@ extern "C" int rt_render_multi(rt_multi *m, const double cam[16], void *root_ful
         M_HIP(hipEventSynchronize(m->ev_t1));
         M_HIP(hipEventElapsedTime(ms, m->ev_t0, m->ev_t1));
     }
+    m->last_full = full;
+    guard.ok = true;
     return RT_OK;
 }
 
@@ -314,8 +324,9 @@ extern "C" int rt_multi_download(rt_multi *m, void *host_dst, size_t bytes)
     if (bytes > m->full_bytes) return fail(RT_ERR_INVALID, "rt_multi_download: %zu bytes requested, the frame holds %zu", bytes, m->full_bytes);
     DeviceRestore restore;
     M_HIP(hipSetDevice(m->dev[0]));
+    if (!m->last_full) return fail(RT_ERR_INVALID, "rt_multi_download: no frame has been rendered yet");
     M_HIP(hipStreamSynchronize(m->s_render[0]));
-    M_HIP(hipMemcpy(host_dst, m->full, bytes, hipMemcpyDeviceToHost));
+    M_HIP(hipMemcpy(host_dst, m->last_full, bytes, hipMemcpyDeviceToHost)); // (the caller's own buffer when the last frame was rendered into one)
     return RT_OK;
 }
 

@@ -50,7 +50,12 @@ static_assert(sizeof(DevObject) == 224, "DevObject layout");
 struct alignas(16) UsEntry {  // RT_CLS_UNITSQ: x2 = y2 = z2 = 1, no cross terms (spheres)
     double kx, ky, kz, c;     // K_X, K_Y, K_Z, K_C
     double r, inv_r;          // bounding radius (+inf: do not cull) and 1 / r  -- culling only
-    uint32_t orig, pad[3];
+    uint32_t orig;
+    // Own-sphere rule of the lean path (rt_wavefront.hip, own_sphere_skippable): a shadow ray that leaves this sphere towards a
+    // directional light in front of the surface cannot be blocked by this very sphere while the reference's own t0 of that test
+    // lies in (own_lo, own_hi).  own_lo = +inf: never skipped.  Derived data, set by rt_create.
+    float own_lo, own_hi;
+    uint32_t pad;
 };                            // 64 B
 struct alignas(16) LinEntry { // no degree-2 terms (planes)
     double kx, ky, kz, c;
@@ -140,6 +145,7 @@ struct FrameArgs {
     uint32_t *tile_state; // [n_tiles], NULL = no scan workgroups
     uint32_t frame_tag;   // unique per frame of this context, never 0, < 2^29
     uint32_t n_scan;      // classifying workgroups in this launch
+    uint32_t lean;        // 1: all-sphere scene without mirrors, dense output: the wave-per-block instantiation renders it (rt_wavefront.hip, "the lean path")
 };
 
 #define RT_TILE 16        // a workgroup renders a 16 x 16 pixel tile

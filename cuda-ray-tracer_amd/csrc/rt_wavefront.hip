@@ -98,9 +98,13 @@ __device__ __forceinline__ uint32_t tile_py(uint32_t tid) { return (tid >> 7) * 
 #ifndef RT_WF_OCC_DELTA
 #define RT_WF_OCC_DELTA 0
 #endif
-template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR>
+#ifndef RT_WF_LEAN_OCC
+#define RT_WF_LEAN_OCC 6
+#endif
+template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR, bool LEAN = false>
 constexpr int wf_occupancy()
 {
+    if (LEAN) return COUNT ? 3 : (RT_FAST ? RT_WF_LEAN_OCC - 1 : RT_WF_LEAN_OCC); // (the FMA build's schedule needs two registers more) // the wave-per-block path (see "the lean path" in the kernel): no hit queue, few live values
     int occ = HAS_CUBIC ? 2 : (HAS_MIRROR ? (HAS_GQ ? 3 : 4) : (HAS_GQ ? 3 : 6)); // 80 / 128 / 168 / ~200 VGPRs (strict, no counters); the
                                                                                   // mirror-free general-quadric one needs 129-130 at 4.
     // Spheres and planes without mirrors run at SIX workgroups per CU (80 VGPRs, and an LDS carve-up that fits six times into 160 KB:
@@ -585,9 +589,9 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
     }
 }
 
-template <bool SPHERICAL>
+template <bool SPHERICAL, typename Light>
 __device__ __forceinline__ unsigned long long relevant_mask(const UsEntry *us, uint32_t base, uint32_t end, const Ball &ball,
-                                                            const DevLight &lt, uint32_t lane)
+                                                            const Light &lt, uint32_t lane)
 {
     const uint32_t j = base + lane;
     return __ballot(j < end && sphere_relevant<SPHERICAL>(us[j], ball, lt));
@@ -611,22 +615,23 @@ constexpr uint32_t CREC_MAX = 64; // culling records cover the first group of 64
 // LDS carve-up (dynamic shared memory), shared by kernel and launcher.
 struct LdsLayout {
     uint32_t scene, light, hp, hn, hdir, park, hidx, hpix, color, shadow, ball, box, crec, n_crec, misc, total, shadow_words;
-    __host__ __device__ LdsLayout(uint32_t scene_bytes, uint32_t n_lights, bool has_mirror, uint32_t n_cull_spheres)
+    __host__ __device__ LdsLayout(uint32_t scene_bytes, uint32_t n_lights, bool has_mirror, uint32_t n_cull_spheres, bool lean = false)
     {
+        const uint32_t Q = lean ? 0u : WG; // the lean path keeps a wave's hits in registers: no queue, no shadow bits, no colour exchange
         n_crec = n_cull_spheres < CREC_MAX ? n_cull_spheres : CREC_MAX; // culling records per chunk (0: culling is off)
         shadow_words = (n_lights + 31) / 32;
         if (shadow_words == 0) shadow_words = 1;
         uint32_t off = 0;
         scene = off; off = align16(off + scene_bytes);
         light = off; off = align16(off + n_lights * (uint32_t) sizeof(DevLight));
-        hp = off; off = align16(off + 3 * WG * 8);
-        hn = off; off = align16(off + 3 * WG * 8);
+        hp = off; off = align16(off + 3 * WG * 8); // (the lean path parks the hit point of each pixel here across the light loop: point lights only read it)
+        hn = off; off = align16(off + 3 * Q * 8);
         hdir = off; off = align16(off + (has_mirror ? 3 * WG * 8 : 0)); // mirrors only: the pixel's incoming direction ...
         park = off; off = align16(off + (has_mirror ? 5 * WG * 4 : 0)); // ... and its running colour / ratio / depth, parked across B and C
-        hidx = off; off = align16(off + WG * 4); // (object << 8) | owner lane
+        hidx = off; off = align16(off + Q * 4); // (object << 8) | owner lane
         hpix = hidx;
-        color = off; off = align16(off + 3 * WG * 4);
-        shadow = off; off = align16(off + WG * shadow_words * 4);
+        color = off; off = align16(off + 3 * Q * 4);
+        shadow = off; off = align16(off + Q * shadow_words * 4);
         ball = off; off = align16(off + 4 * (uint32_t) sizeof(Ball));
         box = off; off = align16(off + 4 * (uint32_t) sizeof(BoxH));
         crec = off; off = align16(off + 4 * n_crec * (uint32_t) sizeof(CullRec));
@@ -639,21 +644,26 @@ constexpr int NO_BLOCKER = 0x7fffffff;
 
 // Phase B for one (chunk, light) item: is the lane's shadow ray blocked, and (COUNT builds) by which lowest
 // object index.  `blocker` keeps the lowest blocking index seen; without COUNT any blocker ends the search.
-template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool SPHERICAL> // SPHERICAL: the light's kind -- one copy of the loop per kind, each without the other's code
+//
+// OWN (the lean path, all-sphere scenes): `own` is the table index of the sphere the lane's hit lies on, and `own_skip` says that the
+// reference's test of this shadow ray against that very sphere is known to find no blocker (own_sphere_skippable in the kernel has the
+// argument), so the lane sits that sphere out; `own_excl` (wave-uniform) has the bit of a sphere that EVERY tested lane may skip.
+template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool SPHERICAL, bool OWN = false, typename Light = DevLight> // SPHERICAL: the light's kind -- one copy of the loop per kind, each without the other's code
 __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj,
-                                              const Mono &sm, double max_t, bool valid, bool prod, const Ball *ballp, const BoxH *boxp, const CullRec *crec, const DevLight &lt,
-                                              uint32_t lane, Cnt<COUNT> &cnt)
+                                              const Mono &sm, double max_t, bool valid, bool prod, const Ball *ballp, const BoxH *boxp, const CullRec *crec, const Light &lt,
+                                              uint32_t lane, Cnt<COUNT> &cnt, uint32_t own = 0, bool own_skip = false, unsigned long long own_excl = 0ull)
 {
     // valid: lanes whose ray is tested.  prod: lanes the product build tests (== valid there); a counting build tests more lanes --
     // all that have a hit -- and counts executed work for the `prod` ones only (wave-level work: if any lane is one).
     const bool prod_any = COUNT ? (bool) __any(prod) : true;
     int blocker = NO_BLOCKER;
-    const bool quad = fabs(sm.u2) > EPS;
+    // (a directional light's rays share their direction: t2 is the same in every lane, and said so the branch on it is a scalar one)
+    const bool quad = SPHERICAL ? fabs(sm.u2) > EPS : __builtin_amdgcn_readfirstlane((int) (fabs(sm.u2) > EPS)) != 0;
     const double four_t2 = 4.0 * sm.u2;
     for (uint32_t base = 0; base < fa.n_us; base += 64) {
         const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
         unsigned long long cand = 0;
-        if (fa.cull) {
+        if (OWN || fa.cull) {
             unsigned long long it;
             if (!SPHERICAL && base == 0) {
                 it = relevant_mask_directional(crec, end, sm.d, lt.inv_uu, lt.len_u, lane); // sm.d is this light's FP32-rounded direction
@@ -664,13 +674,20 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
             }
             else it = relevant_mask<SPHERICAL>(S.us, base, end, *ballp, lt, lane); // (the ball is read from LDS here, not kept)
             if (lane == 0 && prod_any) cnt.cull(SPHERICAL ? C_SHADOW_SPH : C_SHADOW_DIR, end - base);
-            if (prod) cnt.exec(K_US, (unsigned long long) __popcll(it));
+            if (OWN && base == 0) it &= ~own_excl;
+            if (!OWN && prod) cnt.exec(K_US, (unsigned long long) __popcll(it));
             while (it) { // wave-uniform loop over the spheres that survived the culling
                 const int b = __builtin_ctzll(it);
                 it &= it - 1;
+                bool act = valid;
+                if (OWN) { // lanes whose own sphere this is sit it out; nobody left: next sphere
+                    act = valid && !(own_skip && own == base + (uint32_t) b);
+                    if (!__any(act)) continue;
+                    if (prod && act) cnt.exec(K_US, 1);
+                }
                 const UsEntry e = S.us[base + b];
                 const double t1 = us_t1(e, sm), t0 = us_t0(e, sm);
-                const bool need = us_needs_solve(quad, four_t2, t1, t0);
+                const bool need = act && us_needs_solve(quad, four_t2, t1, t0);
                 cand |= need ? (1ull << b) : 0ull;
             }
         } else {
@@ -778,8 +795,10 @@ __device__ __forceinline__ const ColdArgs &cold_args()
 // HAS_MIRROR = some object has reflection_ratio > EPS.  Without mirrors every pixel is finished after round 0, the
 // round loop is known to run once and the bounce state (ray direction, blend ratio, depth) is dead during the shadow
 // phase -- which is what lets the mirror-free instantiation fit 128 VGPRs (4 waves per SIMD).
-template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR>
-__global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MIRROR>())) void wavefront_tile_kernel(
+//
+// LEAN = the wave-per-block path for scenes of unit spheres only (no mirrors, dense output): see "the lean path" below.
+template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR, bool LEAN = false>
+__global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MIRROR, LEAN>())) void wavefront_tile_kernel(
     // The first twelve dwords of the kernel arguments are PRELOADED into SGPRs at wave launch (kernarg preload, gfx940+; the
     // object is built with -amdgpu-kernarg-preload-count=12): with them a workgroup decides what it is in its very first
     // instructions -- an index slot reads its tile's word and, nine times out of ten, leaves without ever fetching the rest.
@@ -848,7 +867,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     const double *__restrict__ camx = cold.camx, *__restrict__ camy = cold.camy;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool NEED_CROSS = HAS_GQ || HAS_CUBIC;
-    const LdsLayout L(fa.stage_bytes, fa.n_lights, HAS_MIRROR, fa.cull ? fa.n_us : 0u);
+    static_assert(!LEAN || (!HAS_GQ && !HAS_CUBIC && !HAS_MIRROR), "the lean path renders unit spheres only");
+    const LdsLayout L(fa.stage_bytes, fa.n_lights, HAS_MIRROR, fa.cull ? fa.n_us : 0u, LEAN);
     const DevObject *gobj = reinterpret_cast<const DevObject *>(gscene); // full object records: global memory only
     SceneLds S; // class tables + materials staged in LDS (only tiles with hits ever stage them); LDS offset = blob offset - off_us
     S.us = reinterpret_cast<const UsEntry *>(smem + L.scene);
@@ -881,6 +901,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     uint32_t *s_decode = s_wcount + 12;                               // [3] what wave 0 decoded from the launch order: tile, flags, cost scale
     uint32_t *s_half = s_wcount + 11;                                 // [1] which half of the tile this workgroup renders (0: all of it)
     uint32_t *s_cost = s_wcount + 9;                                  // [1] round 0: work of the shadow phase, for the next frame's launch order
+    uint32_t *s_done = s_wcount + 15;                                 // [1] lean path: waves of this workgroup that have finished their block
 
     RT_STAMP_DECL
     // No prologue: 83 % of the tiles of a typical frame contain no hit at all, and for those the whole job is
@@ -993,7 +1014,10 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 // A tile without hits writes nothing, so its word may be left over from an older frame of this generation:
                 // the word is only a hint where to look, and the tile counts as covered iff that list entry really names it.
                 const uint32_t cls = w & 31u, pos = w >> 5;
-                if (tstate == ST_TIMEOUT && cls >= 1u && cls <= ORD_CLASSES && pos < hot_n_tiles) { // (NONEMPTY: its classifier already found it uncovered)
+                // (NONEMPTY: its classifier already found it uncovered.  EMPTY: the classifier does not look -- a list slot may still trace a tile
+                // that had hits in the previous frame; it stores the same background a paint workgroup does, but a counting build must
+                // not book the tile's rays twice, so there the index slot looks for itself.)
+                if ((tstate == ST_TIMEOUT || (COUNT && tstate == ST_EMPTY)) && cls >= 1u && cls <= ORD_CLASSES && pos < hot_n_tiles) {
                     const uint32_t k = cls - 1u;
                     uint32_t count = 0;
 #pragma unroll
@@ -1131,11 +1155,184 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             if (tid + WG < tot16) dst[tid + WG] = pre1;
             for (uint32_t i = tid + 2 * WG; i < tot16; i += WG) dst[i] = i < n16 ? stage_scene[i] : stage_light[i - n16];
             staged = true;
+            if (LEAN && tid == 0) { s_done[0] = 0u; s_cost[0] = 0u; s_zero[0] = 0u; if (!(hot_flags & 2u)) s_half[0] = 0u; }
             lds_barrier();
         }
         bool live = inside; // this pixel still has a ray to trace
+        uint32_t ord_cls = 0, ord_pos = 0; // one thread per tile with hits: the tile's entry in the next frame's launch order
+        if constexpr (LEAN) {
+            // ---------------- the lean path: one wave per 8 x 8 block, start to finish ----------------
+            // Scenes of unit spheres without mirrors (BASELINE configs 2 and 5).  A wave keeps the hits of its own 64 pixels IN
+            // REGISTERS -- no compaction into a queue of the tile, hence no barrier after the staging one, no shadow bits, no colour
+            // exchange -- and walks the lights IN ORDER, adding each unshadowed light's term to the pixel's colour as soon as its
+            // shadow test is done (src/update-cpu.cpp:62-77 is that very loop).  What the queue bought (full lanes in the shadow phase
+            // of tiles on a silhouette) is small where spheres cover many blocks: 1080p has 3.5 % more (block, light) items this way.
+            // What it cost: five barriers per tile, 12 KB of LDS, the one-lane-per-hit shading phase and its second pass over the
+            // normals and lights (10 % of the wave-cycles), the bits in between.
+            if (inside) cnt.add(0);
+            cnt.primary_traced();
+            RT_STAMP(1);
+            double best_t;
+            int best;
+            {
+                Mono m;
+                mono_set_o<false>(m, o);
+                mono_set_d<false>(m, dir);
+                mono_set_od<false>(m);
+                nearest<COUNT, false, false, true>(fa, S, gobj, m, live, lane, best_t, best, cnt);
+            }
+            RT_STAMP(2);
+            if (live) cnt.add(3, fa.n_obj);
+            const bool hit = live && best >= 0;
+            const unsigned long long hm = __ballot(hit);
+            RT_STAMP_INFO(((unsigned long long) tile << 32) | (unsigned) __popcll(hm));
+            unsigned long long b_ticks = 0ull;
+            if (hm != 0ull) { // wave-uniform: this block has hits
+                const uint32_t bi = hit ? (uint32_t) best : 0u; // (every object is a unit sphere: table index == object index)
+                const UsEntry eo = S.us[bi];
+                const D3 sp{o.x + best_t * dir.x, o.y + best_t * dir.y, o.z + best_t * dir.z};
+                const D3 sn = sphere_normal(eo, sp);
+                if (hit) cnt.add(4);
+                hp[tid] = sp.x; hp[WG + tid] = sp.y; hp[2 * WG + tid] = sp.z; // this lane's own slot: only point lights need the hit point again
+                Mono sm;
+                mono_set_o<false>(sm, D3{sp.x + SHADOW_BIAS * sn.x, sp.y + SHADOW_BIAS * sn.y, sp.z + SHADOW_BIAS * sn.z});
+                // own_sphere_skippable.  The shadow ray of a hit on sphere s starts at o = p + 1e-2 n, outside s, and the reference tests it
+                // against s like against any other object (src/update-cpu.cpp:66-71).  Its t0 = F_s(o) does not depend on the light, so it
+                // is formed here once, with the reference's operations (us_t0).  For a directional light in front of the surface
+                // ((float) dot(n, l) > 0: the lanes the product traces at all) with |d|^2 > EPS that test cannot find a root > EPS while
+                // own_lo < t0 < own_hi:
+                //   * its computed t1 is 2 rho (n.d) up to rounding, rho = |o - centre|, and n.d >= -1.1e-7 |d| (dot(n, l) > 0 up to 3 ulp;
+                //     d is l rounded to FP32), so either t1 > 0 -- then, t0 being > 0, both roots are <= 0 (us_needs_solve) --
+                //   * or t1^2 <= 2 (2.2e-7 rho |d|)^2 + 2 (2.7e-15 S |d|)^2  with rho^2 = t0 + r^2 < 3 (r^2 + 1)  (t0 < own_hi = (r + 1)^2)  and
+                //     S = |o|_1 + |centre|_1 <= 2 |centre|_1 + 3 r + 3, which is below 4 |d|^2 t0 as soon as t0 > 1e-13 (r^2 + 1) + 1e-29 S^2:
+                //     the discriminant is negative and the solver returns -1 (include/surface_impl.h:141-144).
+                // own_lo = 1e-10 (r^2 + 1) + 1e-20 S^2 keeps three orders of magnitude between the two (rt_create); a true t0 is
+                // 0.02 r + 1e-4.  Lanes outside the window simply take the test.
+                const double t0_own = us_t0(eo, sm);
+                const bool skip_geom = hit && t0_own > (double) eo.own_lo && t0_own < (double) eo.own_hi;
+                const uint32_t b0 = (uint32_t) __builtin_amdgcn_readlane((int) bi, __builtin_ctzll(hm));
+                // every hit of the block on one sphere, all inside the window: the sphere's bit, cleared from the culling verdict at once
+                const unsigned long long own_all = (__ballot(hit && (bi != b0 || !skip_geom)) == 0ull && b0 < 64u) ? (1ull << b0) : 0ull;
+
+                // ---- the block's bounding box / ball and its culling records (phase A' of the other path), private to this wave ----
+                {
+                    const float inf = __builtin_inff();
+                    const float lox = wave_min_f(hit ? __double2float_rd(sp.x) : inf), hix = wave_max_f(hit ? __double2float_ru(sp.x) : -inf);
+                    const float loy = wave_min_f(hit ? __double2float_rd(sp.y) : inf), hiy = wave_max_f(hit ? __double2float_ru(sp.y) : -inf);
+                    const float loz = wave_min_f(hit ? __double2float_rd(sp.z) : inf), hiz = wave_max_f(hit ? __double2float_ru(sp.z) : -inf);
+                    const double dx = (double) hix - (double) lox, dy = (double) hiy - (double) loy, dz = (double) hiz - (double) loz;
+                    Ball b;
+                    b.cx = 0.5 * ((double) lox + (double) hix);
+                    b.cy = 0.5 * ((double) loy + (double) hiy);
+                    b.cz = 0.5 * ((double) loz + (double) hiz);
+                    b.R = 0.5 * sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-9) + 1.01e-2; // half diagonal (rounded up) + the shadow bias of the ray origins
+                    if (lane == 0) {
+                        sball[wave] = b;
+                        sbox[wave] = BoxH{0.5 * dx * (1.0 + 1e-9) + 1.01e-2, 0.5 * dy * (1.0 + 1e-9) + 1.01e-2, 0.5 * dz * (1.0 + 1e-9) + 1.01e-2, 0.0};
+                    }
+                    if (lane < L.n_crec) screc[wave * L.n_crec + lane] = cull_record(S.us[lane], b);
+                    if (lane == 0) cnt.cull(C_RECORDS, L.n_crec);
+                    // (written and read by this wave only; LDS executes a wave's accesses in order)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+                }
+                RT_STAMP(5);
+
+                // ---- lights in order: shadow test, then the light's term (src/update-cpu.cpp:62-77) ----
+                const unsigned long long b_t0 = listing ? __builtin_amdgcn_s_memtime() : 0ull;
+                const MatEntry mt = S.mat[bi];
+                const F3 aop{mt.albedo[0] / PI_F, mt.albedo[1] / PI_F, mt.albedo[2] / PI_F}; // object_color / pi, once per hit
+                F3 acc{0.0f, 0.0f, 0.0f};
+                const CullRec *my_crec = reinterpret_cast<const CullRec *>(smem + (L.crec + wave * L.n_crec * (uint32_t) sizeof(CullRec)));
+                // (the lights through the constant address space: scalar loads, their fields in SGPRs -- no vector register holds a
+                // per-light constant.  The LDS copy of the lights is not used by this path.)
+                typedef const __attribute__((address_space(4))) DevLight *ConstLights;
+                ConstLights clight = (ConstLights) glight;
+                for (uint32_t l = 0; l < fa.n_lights; l++) {
+                    const auto &lt = clight[l];
+                    const bool lt_spherical = lt.spherical != 0;
+                    const bool lt_backface_exact = lt.backface_exact != 0;
+                    if (hit) cnt.add(1);
+                    bool wanted = hit; // the lanes the product build traces (see the same place in the other path)
+                    bool own_skip = false;
+                    unsigned long long own_excl = 0ull;
+                    if (lt_backface_exact) { // directional, all colours finite: a light behind the surface adds exactly +0, shadowed or not
+                        const float lam = (float) dot3(sn, D3{lt.p[0], lt.p[1], lt.p[2]});
+                        wanted = hit && (0.0f < lam);
+                        if (!COUNT && !__any(wanted)) continue;
+                        own_skip = wanted && skip_geom;
+                        own_excl = COUNT ? 0ull : own_all;
+                    }
+                    double max_t;
+                    if (lt_spherical) {
+                        max_t = 1.0; // shadow_ray, include/light_impl.h:19-21: (light - point) through FP32
+                        const D3 sp{hp[tid], hp[WG + tid], hp[2 * WG + tid]};
+                        const double dx = lt.p[0] - sp.x, dy = lt.p[1] - sp.y, dz = lt.p[2] - sp.z;
+                        const double q = dot3(sn, D3{dx, dy, dz});
+                        const double mag = fabs(sn.x * dx) + fabs(sn.y * dy) + fabs(sn.z * dz);
+                        wanted = hit && !(q < -1e-9 * mag); // behind the surface by a margin 10^7 times the rounding: the term is +0 (as in the other path)
+                        if (!COUNT && !__any(wanted)) continue;
+                        const D3 sd{(double) (float) dx, (double) (float) dy, (double) (float) dz};
+                        mono_set_d<false>(sm, sd);
+                    } else {
+                        max_t = 1e6; // include/light_impl.h:23-25: the per-light constant direction and its monomials
+                        sm.d = D3{lt.sdir[0], lt.sdir[1], lt.sdir[2]};
+                        sm.dxx = lt.dxx; sm.dyy = lt.dyy; sm.dzz = lt.dzz;
+                        sm.u2 = lt.u2;
+                    }
+                    mono_set_od<false>(sm);
+                    if (wanted) cnt.traced();
+                    int blocker;
+                    if (lt_spherical) {
+                        blocker = shadow_blocker<COUNT, false, false, true, true>(fa, S, gobj, sm, max_t, COUNT ? hit : wanted, wanted, sball + wave, sbox + wave, my_crec, lt, lane, cnt);
+                    } else {
+                        // (|d|^2 <= EPS: the reference takes its linear branch, to which the own-sphere argument does not apply)
+                        const bool quad_l = __builtin_amdgcn_readfirstlane((int) (fabs(sm.u2) > EPS)) != 0;
+                        blocker = shadow_blocker<COUNT, false, false, false, true>(fa, S, gobj, sm, max_t, COUNT ? hit : wanted, wanted, sball + wave, sbox + wave, my_crec, lt, lane,
+                                                                                   cnt, bi, own_skip && quad_l, quad_l ? own_excl : 0ull);
+                    }
+                    if (hit) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
+                    if (hit && blocker == NO_BLOCKER && (wanted || !lt_backface_exact)) {
+                        const double lp[3] = {lt.p[0], lt.p[1], lt.p[2]};
+                        const float lc[3] = {lt.color[0], lt.color[1], lt.color[2]};
+                        D3 spl{0.0, 0.0, 0.0};
+                        if (lt_spherical) spl = D3{hp[tid], hp[WG + tid], hp[2 * WG + tid]};
+                        const F3 col = surface_color_pre(lp, lc, lt_spherical, spl, sn, aop);
+                        cnt.shaded();
+                        acc.x += col.x;
+                        acc.y += col.y;
+                        acc.z += col.z;
+                    }
+                }
+                if (hit) { // glm::min(vec3(1.0f), acc), src/update-cpu.cpp:77
+                    res.x = (acc.x < 1.0f) ? acc.x : 1.0f;
+                    res.y = (acc.y < 1.0f) ? acc.y : 1.0f;
+                    res.z = (acc.z < 1.0f) ? acc.z : 1.0f;
+                }
+                if (listing) b_ticks = __builtin_amdgcn_s_memtime() - b_t0;
+                RT_STAMP(6);
+            }
+            // ---- the next frame's launch order: the last wave of the workgroup to get here speaks for the tile ----
+            // cost = shader-clock ticks / 64 its waves spent on their lights, summed (what the tile takes of its CU)
+            if (ord_wr && lane == 0) { // launch-uniform x one lane per wave
+                if (hm != 0ull) __hip_atomic_fetch_add(&s_cost[0], (uint32_t) (b_ticks >> 6) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t before = __hip_atomic_fetch_add(&s_done[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (before == 3u) {
+                    const uint32_t cost = __hip_atomic_load(&s_cost[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (cost != 0u) { // the tile has hits
+                        if (((tile * 0x9E3779B1u) >> 28) == 0u) atomicAdd(&ord_wr[16], 1u); // census, also while the ordering is off
+                        if (listing) {
+                            const uint32_t q = cost_scale ? (uint32_t) (((unsigned long long) cost * ORD_CLASSES) / ((unsigned long long) cost_scale + 1ull)) : ORD_CLASSES - 1u;
+                            ord_cls = ORD_CLASSES - (q < ORD_CLASSES - 1u ? q : ORD_CLASSES - 1u); // class + 1
+                            ord_pos = atomicAdd(&ord_wr[ord_cls - 1u], 1u);
+                            if (cost > cost_scale - cost_scale / 4u) atomicMax(&ord_wr[17], cost);
+                        }
+                    }
+                }
+            }
+        } else {
         bool first = true;
-        uint32_t ord_cls = 0, ord_pos = 0; // thread 0: this tile's entry in the next frame's launch order
         if (fa.sparse && tid == 0) s_sparse[0] = 0xFFFFFFFFu; // visible after the first barrier of round 0
         if (!(hot_flags & 2u) && tid == 0) s_half[0] = 0u;    // (with the lists on, wave 0 wrote it with the decode)
         if (tid == 0) s_zero[0] = 0u;
@@ -1421,15 +1618,16 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             RT_STAMP(9);
             if (!more) break;
         }
+        } // !LEAN
 
         // the pixel's coordinates are formed again here (from an opaque copy of tid) instead of being kept in registers
         // through all the rounds; one more lever that keeps the mirror instantiations free of scratch spills
         // ... and so are the frame's sizes: read through a fresh pointer to the arguments, they are short-lived scalar loads here instead of
         // SGPRs (or, as it happened, a spill slot that was rematerialised away but still cost the kernel a private segment) across all phases
         // (Only where registers are the limit -- spheres and planes without mirrors, six workgroups per CU; the other instantiations lose a per cent with it.)
-        constexpr bool LEAN = !HAS_GQ && !HAS_CUBIC && !HAS_MIRROR;
-        const FrameArgs &fe = LEAN ? cold_args().fa : fa;
-        const uint32_t tid_ = LEAN ? tid ^ s_zero[0] : tid; // (an LDS word that is always 0: the compiler cannot know, so it cannot keep x / y of round 0 alive instead)
+        constexpr bool LEAN_REGS = !HAS_GQ && !HAS_CUBIC && !HAS_MIRROR;
+        const FrameArgs &fe = LEAN_REGS ? cold_args().fa : fa;
+        const uint32_t tid_ = LEAN_REGS ? tid ^ s_zero[0] : tid; // (an LDS word that is always 0: the compiler cannot know, so it cannot keep x / y of round 0 alive instead)
         const uint32_t sx_ = (tile % fe.tiles_x) * RT_TILE + tile_px(tid_), sy_ = (tile / fe.tiles_x) * RT_TILE + tile_py(tid_);
         if (fe.sparse) { // launch-uniform: fb is a message (rt_pack_sparse's layout); only tiles with round-0 hits are in it
             const uint32_t mslot = s_sparse[0]; // workgroup-uniform
@@ -1474,9 +1672,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
 
 } // namespace RT_SYM(rtw)
 
-extern "C" size_t RT_SYM(rt_wavefront_lds_bytes)(uint32_t stage_bytes, uint32_t n_lights, int has_mirror, uint32_t n_cull_spheres)
+extern "C" size_t RT_SYM(rt_wavefront_lds_bytes)(uint32_t stage_bytes, uint32_t n_lights, int has_mirror, uint32_t n_cull_spheres, int lean)
 {
-    return RT_SYM(rtw)::LdsLayout(stage_bytes, n_lights, has_mirror != 0, n_cull_spheres).total;
+    return RT_SYM(rtw)::LdsLayout(stage_bytes, n_lights, has_mirror != 0, n_cull_spheres, lean != 0).total;
 }
 
 // One workgroup per 16x16 tile; the dispatcher hands tiles to CUs as they free up, which is the dynamic load
@@ -1495,9 +1693,12 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
     // index region: groups of one paint workgroup + RT_PAINT_TILES index slots (the last group may be partial: surplus slots leave)
     const uint32_t n_index = n_paint ? n_paint * (RT_PAINT_TILES + 1u) : fa->n_tiles;
     const dim3 grid(n_scan + ((fa->order_state && fa->ord_on) ? fa->ord_cap : 0u) + n_index), block(WG);
-    const size_t lds = LdsLayout(fa->stage_bytes, fa->n_lights, fa->has_mirror != 0, fa->cull ? fa->n_us : 0u).total;
     const unsigned char *gs = reinterpret_cast<const unsigned char *>(gobj);
-    const int sel = (count ? 8 : 0) | (fa->has_mirror ? 4 : 0) | (fa->n_gq ? 2 : 0) | (fa->n_cub ? 1 : 0);
+    int sel = (count ? 8 : 0) | (fa->has_mirror ? 4 : 0) | (fa->n_gq ? 2 : 0) | (fa->n_cub ? 1 : 0);
+    // the lean path (rt_render decides: unit spheres only, all cullable, no mirrors, dense output): instantiations 16 / 17
+    const bool lean = fa->lean && (sel & 7) == 0 && fa->all_cullable && fa->n_us == fa->n_obj && !fa->sparse;
+    if (lean) sel = count ? 17 : 16;
+    const size_t lds = LdsLayout(fa->stage_bytes, fa->n_lights, fa->has_mirror != 0, fa->cull ? fa->n_us : 0u, lean).total;
     const bool ordering = fa->order_state && fa->ord_on;
     const unsigned char *hot_us = gs + fa->off_us;
     const uint32_t *hot_ord_rd = ordering ? fa->order_state + (size_t) fa->ord_read * fa->ord_stride : nullptr;
@@ -1558,7 +1759,9 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
     case 12: RT_LAUNCH(true, true, false, false); break;
     case 13: RT_LAUNCH(true, true, false, true); break;
     case 14: RT_LAUNCH(true, true, true, false); break;
-    default: RT_LAUNCH(true, true, true, true); break;
+    case 15: RT_LAUNCH(true, true, true, true); break;
+    case 16: hipLaunchKernelGGL((wavefront_tile_kernel<false, false, false, false, true>), grid, block, lds, stream, hot_us, hot_ord_rd, fa->n_us, fa->ord_cap, fa->n_tiles, hot_flags, n_scan ? fa->tile_state : nullptr, fa->frame_tag, n_scan, cold); break;
+    default: hipLaunchKernelGGL((wavefront_tile_kernel<true, false, false, false, true>), grid, block, lds, stream, hot_us, hot_ord_rd, fa->n_us, fa->ord_cap, fa->n_tiles, hot_flags, n_scan ? fa->tile_state : nullptr, fa->frame_tag, n_scan, cold); break;
     }
 #undef RT_LAUNCH
     return hipGetLastError();

@@ -31,7 +31,11 @@ __device__ __forceinline__ bool needs_solve(double t2, double t1, double t0)
 // divisions need not be executed.  This removes the "own sphere" solve of every shadow ray that leaves a lit surface.
 __device__ __forceinline__ bool us_needs_solve(bool quad, double four_t2, double t1, double t0)
 {
-    if (quad) return !(t1 * t1 - four_t2 * t0 < 0) && !(t1 > 0.0 && t0 > 0.0);
+    if (quad) { // (no short-circuit: three compares and two mask operations instead of a divergent branch inside the callers' loops)
+        const bool no_root = t1 * t1 - four_t2 * t0 < 0;
+        const bool away = (t1 > 0.0) & (t0 > 0.0);
+        return !(no_root | away);
+    }
     return fabs(t1) > EPS;
 }
 
@@ -238,8 +242,9 @@ struct Ball {
     double cx, cy, cz, R;
 };
 
-template <bool SPHERICAL> // the light's kind, known to the caller (wave-uniform): only that half is compiled into the loop
-__device__ __forceinline__ bool sphere_relevant(const UsEntry &e, const Ball &ball, const DevLight &lt)
+template <bool SPHERICAL, typename Light> // the light's kind, known to the caller (wave-uniform): only that half is compiled into the loop.  Light: a DevLight in
+                                           // LDS, or in the constant address space (the lean path reads the lights with scalar loads)
+__device__ __forceinline__ bool sphere_relevant(const UsEntry &e, const Ball &ball, const Light &lt)
 {
     bool rel = false;
     const double r = e.r;

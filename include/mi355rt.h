@@ -78,6 +78,9 @@ typedef struct rt_scene_desc {
 #define RT_FLAG_NOSPLIT 128u   /* wavefront kernel: every tile is rendered by one workgroup (default: the costliest tiles of the previous frame
                                * by two, one per half tile) -- for A/B */
 
+#define RT_FLAG_NOLEAN 256u    /* wavefront kernel: scenes of unit spheres without mirrors are rendered by the general instantiation (hit queue per
+                               * tile) instead of the wave-per-block one; same results, for A/B runs and as a cross-check */
+
 /* rt_config.format -- framebuffer pixel format */
 #define RT_FMT_RGBA32F 0u     /* 4 x float per pixel, alpha 1.0: the un-quantised colours the CPU back end
                                  produces (src/update-cpu.cpp:128-131) plus an alpha lane for 16-byte stores */
@@ -175,7 +178,9 @@ int rt_create(rt_ctx **out, const rt_scene_desc *scene, const rt_config *cfg);
  * tile words), so its frames run in the order they were issued: on one stream that is automatic, and when a call passes a
  * different stream than the previous one, that stream first waits for the previous frame (an event recorded behind every
  * render).  The state affects speed only, never the image.
- * Stream capture: with ms == NULL and the stream of the previous call, rt_render only enqueues (one kernel, one event record), so a
+ * Stream capture: with ms == NULL and the stream of the previous call, rt_render only enqueues (one kernel; the ordering event is
+ * not recorded while the stream is capturing -- a context whose frames were captured must stay on that stream afterwards, a call on
+ * another stream is refused with RT_ERR_INVALID), so a
  * sequence of K frames can be captured into one hipGraph and launched at once -- bench.py times its frames that way (the ~3 us the
  * command processor needs between two dependent launches disappear: 42 instead of 45 us per 1080p frame).  Every captured call
  * carries its own arguments (camera, launch-order generation, frame tag): launched once, in place of the K calls, the graph is

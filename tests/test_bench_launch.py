@@ -58,6 +58,13 @@ def test_rccl_path_with_one_rank(gather):
     assert p.returncode == 0, p.stderr[-3000:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1
+    # the distributed path measures BASELINE config 5 (the 8K frame) and carries its own 1-GPU denominator and the link bound
+    assert "config5" in r["config"]["workload"] and "7680x4320" in r["config"]["workload"] and r["scaling"] == "strong"
+    assert r["one_gpu_same_frame"]["rgba32f_ms"] > 0 and r["one_gpu_same_frame"]["rgba8_ms"] > 0
+    sp = r["speedup_vs_1gpu_config5"]
+    assert 0.2 < sp["rgba32f_dense"] < 1.5 and sp["rgba8_sparse" if gather == "sparse" else "rgba8"] > 0   # one rank: about 1, less the transport
+    assert r["links_into_rank0"]["gather_ingest_gbs"] > 0 and r["gather_bound_ms"]["rgba32f_dense"] == 0.0   # (world 1: nothing arrives from other ranks)
+    assert set(r["predicted_rgba32f_dense"]["table"]) >= {"n2_link50GBs", "n8_link75GBs"}
     assert r["config"]["framebuffer_format"] == "rgba32f"
     assert r["config"]["gathered_frame_identical_to_single_gpu_frame"] is True
     assert r["config"]["gather"]["kind"] == "dense rows"
@@ -91,3 +98,9 @@ def test_timed_region_as_one_graph_or_as_plain_launches(graph):
     assert roof["timed_region"].startswith("one hipGraph of the K = 7 frame launches" if graph else "K launches")
     assert roof["timed_region_last_frame_identical_to_plain_launch"] is True
     assert r["steps"] == 7 and r["n_gpus"] == 1 and roof["kernel_ms"] > 0
+    # all five BASELINE configs on this GPU in the same line, and what update() returns for one synchronised frame
+    assert [c["config"] for c in r["configs"]] == ["config1", "config2", "config3", "config4", "config5"]
+    for c in r["configs"]:
+        assert c["ms_per_step"] > 0 and c["single_frame_ms"] > 0 and c["value"] > 0 and 0 < c["roofline"]["frac"] < 1
+    assert r["single_frame_ms"] == r["configs"][1]["single_frame_ms"]
+    assert "config2" in r["config"]["workload"] and "1920x1080" in r["config"]["workload"]

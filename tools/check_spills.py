@@ -34,8 +34,8 @@ def parse(label, text):
         if m and name:
             row[m.group(1).strip()] = int(m.group(2))
             if m.group(1).strip().startswith("LDS Size"):
-                t = re.search(r"ILb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
-                tag = "<count=%s gq=%s cubic=%s mirror=%s>" % t.groups() if t else name[:40]
+                t = re.search(r"ILb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
+                tag = "<count=%s gq=%s cubic=%s mirror=%s lean=%s>" % t.groups() if t else name[:40]
                 spills = row.get("VGPRs Spill", 0)
                 print(f"{label:28s} {tag:40s} VGPRs {row.get('VGPRs', 0):3d}  occupancy {row.get('Occupancy', 0)}  SGPR spills {row.get('SGPRs Spill', 0):3d}"
                       f"  VGPR spills {spills:3d}  scratch {row.get('ScratchSize', 0)}" + ("   <-- VGPR SPILL" if spills else ("   <-- PRIVATE SEGMENT" if row.get('ScratchSize', 0) else "")))

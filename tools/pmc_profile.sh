@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 run() {
   name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$R/$OUT/$name" -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-orbit --no-graph > "$R/$OUT/$name.log" 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$R/$OUT/$name" -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-orbit --no-configs --no-graph > "$R/$OUT/$name.log" 2>&1
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 run sq2 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE

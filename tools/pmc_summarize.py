@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
             if pat in row.get("Kernel_Name", ""):
                 acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 print(f"# kernel_source_digest {bench.kernel_source_digest()}")
-print(f"# separate rocprofv3 --pmc passes of `python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-orbit` (tools/pmc_profile.sh); per-dispatch means over the launches of {pat}")
+print(f"# separate rocprofv3 --pmc passes of `python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-orbit --no-configs --no-graph` (tools/pmc_profile.sh); per-dispatch means over the launches of {pat}")
 for k in sorted(acc):
     v = acc[k]
     print(f"{k:28s} mean {sum(v)/len(v):16.1f}   n={len(v)}")

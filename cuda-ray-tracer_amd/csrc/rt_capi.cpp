@@ -513,10 +513,27 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
         for (uint32_t k = 0; k < sd->n_objects * 3u && finite; k++) finite = std::isfinite(sd->albedo[k]);
         l.backface_exact = (!l.spherical && finite) ? 1u : 0u;
     }
+    std::vector<LightK> lightk(sd->n_lights); // the same lights as the lean path reads them (rt_scene_dev.h)
+    for (uint32_t i = 0; i < sd->n_lights; i++) {
+        const DevLight &l = lights[i];
+        LightK &k = lightk[i];
+        std::memset(&k, 0, sizeof(k));
+        for (int c = 0; c < 3; c++) { k.p[c] = l.p[c]; k.sdir[c] = l.sdir[c]; k.color[c] = l.color[c]; }
+        k.u2 = l.u2; k.inv_uu = l.inv_uu; k.len_u = l.len_u;
+        k.four_u2 = 4.0 * l.u2;
+        k.s_yz = std::fabs(l.sdir[1]) + std::fabs(l.sdir[2]);
+        k.s_xz = std::fabs(l.sdir[0]) + std::fabs(l.sdir[2]);
+        k.s_xy = std::fabs(l.sdir[0]) + std::fabs(l.sdir[1]);
+        k.flags = (l.spherical ? 1u : 0u) | (l.backface_exact ? 2u : 0u) | (std::fabs(l.u2) > 1e-7 ? 4u : 0u); // EPS of include/surface_impl.h:16,138
+    }
 
     // the wave-per-block instantiation: unit spheres only, every one with a bounding radius, no mirror (sparse frames take the other one)
     ctx->lean_ok = !(cfg.flags & (RT_FLAG_SIMPLE | RT_FLAG_NOLEAN)) && fa.all_cullable && fa.n_us == sd->n_objects && !fa.has_mirror && fa.n_gq == 0 && fa.n_lin == 0 &&
                    fa.n_cub == 0;
+    if (sd->n_lights > 64u) ctx->lean_ok = false; // (its point-light pass keeps one bit per light and lane)
+    fa.pt_mask[0] = fa.pt_mask[1] = 0u;
+    for (uint32_t i = 0; i < sd->n_lights && i < 64u; i++)
+        if (sd->light_is_spherical[i]) fa.pt_mask[i >> 5] |= 1u << (i & 31u);
     if (std::getenv("MI355RT_NOLEAN")) ctx->lean_ok = false; // (experiments)
     if (ctx->lean_ok) ctx->ord_split = 0u; // its waves are independent: a second workgroup per tile would shorten nothing
     if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u, 0) > 160u * 1024u) {
@@ -530,12 +547,13 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
     };
     const size_t fb_bytes = (size_t) (ctx->local_rows ? ctx->local_rows : 1) * sd->width * ctx->pixel_bytes;
     hip_ok(hipMalloc((void **) &ctx->d_obj, blob.size()), "hipMalloc(scene)") &&
-        hip_ok(hipMalloc((void **) &ctx->d_light, sizeof(DevLight) * (lights.size() ? lights.size() : 1)), "hipMalloc(lights)") &&
+        hip_ok(hipMalloc((void **) &ctx->d_light, (sizeof(DevLight) + sizeof(LightK)) * (lights.size() ? lights.size() : 1)), "hipMalloc(lights)") &&
         hip_ok(hipMalloc(&ctx->d_fb, fb_bytes), "hipMalloc(framebuffer)") &&
         hip_ok(hipMalloc((void **) &ctx->d_counters, sizeof(unsigned long long) * 64), "hipMalloc(counters)") &&
         hip_ok(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * 64), "hipMemset(counters)") &&
         hip_ok(hipMemcpy(ctx->d_obj, blob.data(), blob.size(), hipMemcpyHostToDevice), "hipMemcpy(scene)") &&
         hip_ok(lights.empty() ? hipSuccess : hipMemcpy(ctx->d_light, lights.data(), sizeof(DevLight) * lights.size(), hipMemcpyHostToDevice), "hipMemcpy(lights)") &&
+        hip_ok(lights.empty() ? hipSuccess : hipMemcpy(ctx->d_light + lights.size(), lightk.data(), sizeof(LightK) * lightk.size(), hipMemcpyHostToDevice), "hipMemcpy(light table)") &&
         hip_ok(hipEventCreate(&ctx->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&ctx->ev1), "hipEventCreate") &&
         hip_ok(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming), "hipEventCreate");
     if (rc != RT_OK) return rc;

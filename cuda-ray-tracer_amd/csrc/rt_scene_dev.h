@@ -89,6 +89,22 @@ struct alignas(16) DevLight {
 };                                       // 144 B
 static_assert(sizeof(DevLight) == 144, "DevLight layout");
 
+// One light as the lean path of the wavefront kernel reads it: through the constant address space, all of it in one batch of scalar
+// loads, so that a directional light's constants live in SGPRs and never in a vector register.  The table follows the DevLight
+// array in the same allocation ([DevLight x n][LightK x n]).
+struct alignas(64) LightK {
+    double p[3];        // LightSource::p
+    double sdir[3];     // (double) (float) p: a directional light's shadow-ray direction (include/light_impl.h:23-25)
+    double u2;          // |sdir|^2 as the reference sums it
+    double inv_uu, len_u; // culling only (DevLight)
+    double four_u2;     // 4.0 * u2: the factor of t0 in the discriminant (include/surface_impl.h:139)
+    double s_yz, s_xz, s_xy; // |sdir.y| + |sdir.z|, |sdir.x| + |sdir.z|, |sdir.x| + |sdir.y|: the box stage of the culling
+    float color[3];     // LightSource::light_color
+    uint32_t flags;     // 1 spherical   2 backface_exact (DevLight)   4 |sdir|^2 > EPS (the reference solves a quadratic for this light's rays)
+    uint32_t pad[2];
+};                      // 128 B: two 64-byte scalar loads
+static_assert(sizeof(LightK) == 128, "LightK layout");
+
 // Per-launch constants (kernel argument, lands in SGPRs).
 struct FrameArgs {
     double cam[16];      // camera-to-world, column-major
@@ -146,6 +162,7 @@ struct FrameArgs {
     uint32_t frame_tag;   // unique per frame of this context, never 0, < 2^29
     uint32_t n_scan;      // classifying workgroups in this launch
     uint32_t lean;        // 1: all-sphere scene without mirrors, dense output: the wave-per-block instantiation renders it (rt_wavefront.hip, "the lean path")
+    uint32_t pt_mask[2];  // lean path: bit l = light l is a point light (at most 64 lights there; scenes with more take the general instantiation)
 };
 
 #define RT_TILE 16        // a workgroup renders a 16 x 16 pixel tile

@@ -623,7 +623,7 @@ struct LdsLayout {
         if (shadow_words == 0) shadow_words = 1;
         uint32_t off = 0;
         scene = off; off = align16(off + scene_bytes);
-        light = off; off = align16(off + n_lights * (uint32_t) sizeof(DevLight));
+        light = off; off = align16(off + (lean ? 0u : n_lights * (uint32_t) sizeof(DevLight))); // (the lean path reads the lights through scalar loads)
         hp = off; off = align16(off + 3 * WG * 8); // (the lean path parks the hit point of each pixel here across the light loop: point lights only read it)
         hn = off; off = align16(off + 3 * Q * 8);
         hdir = off; off = align16(off + (has_mirror ? 3 * WG * 8 : 0)); // mirrors only: the pixel's incoming direction ...
@@ -659,7 +659,8 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
     int blocker = NO_BLOCKER;
     // (a directional light's rays share their direction: t2 is the same in every lane, and said so the branch on it is a scalar one)
     const bool quad = SPHERICAL ? fabs(sm.u2) > EPS : __builtin_amdgcn_readfirstlane((int) (fabs(sm.u2) > EPS)) != 0;
-    const double four_t2 = 4.0 * sm.u2;
+    double four_t2 = 4.0 * sm.u2;
+    if constexpr (OWN && !SPHERICAL) four_t2 = lt.four_u2; // (the light table has it: the same product, in SGPRs)
     for (uint32_t base = 0; base < fa.n_us; base += 64) {
         const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
         unsigned long long cand = 0;
@@ -668,7 +669,8 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
             if (!SPHERICAL && base == 0) {
                 it = relevant_mask_directional(crec, end, sm.d, lt.inv_uu, lt.len_u, lane); // sm.d is this light's FP32-rounded direction
                 if (__popcll(it) >= BOX_STAGE_MIN) { // wave-uniform: many got through the ball -- look again with the box
-                    it &= __ballot(lane < end && crec_in_box_shadow(crec[lane], *boxp, sm.d));
+                    if constexpr (OWN) it &= __ballot(lane < end && crec_in_box_shadow(crec[lane], *boxp, sm.d, lt.s_yz, lt.s_xz, lt.s_xy));
+                    else it &= __ballot(lane < end && crec_in_box_shadow(crec[lane], *boxp, sm.d));
                     if (lane == 0 && prod_any) cnt.cull(C_SHADOW_DIR, BOX_EVAL_UNITS * (end - base)); // 30 counted operations: three directional decisions
                 }
             }
@@ -1134,7 +1136,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         // camera-table reads.  Two 16-byte pieces per thread cover 8 KB of tables + lights; larger scenes copy the rest the ordinary way.
         const uint4 *stage_scene = reinterpret_cast<const uint4 *>(gscene + fa.off_us);
         const uint4 *stage_light = reinterpret_cast<const uint4 *>(glight);
-        const uint32_t n16 = fa.stage_bytes / 16, tot16 = n16 + fa.n_lights * (uint32_t) (sizeof(DevLight) / 16);
+        const uint32_t n16 = fa.stage_bytes / 16, tot16 = n16 + (LEAN ? 0u : fa.n_lights * (uint32_t) (sizeof(DevLight) / 16));
         uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
         if (tid < tot16) pre0 = tid < n16 ? stage_scene[tid] : stage_light[tid - n16];
         if (tid + WG < tot16) pre1 = tid + WG < n16 ? stage_scene[tid + WG] : stage_light[tid + WG - n16];
@@ -1241,70 +1243,93 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
 
                 // ---- lights in order: shadow test, then the light's term (src/update-cpu.cpp:62-77) ----
                 const unsigned long long b_t0 = listing ? __builtin_amdgcn_s_memtime() : 0ull;
+                const CullRec *my_crec = reinterpret_cast<const CullRec *>(smem + (L.crec + wave * L.n_crec * (uint32_t) sizeof(CullRec)));
+                // The lights through the constant address space (LightK, rt_scene_dev.h): one batch of scalar loads per light, its fields in
+                // SGPRs -- no vector register holds a per-light constant; the LDS copy of the lights is not used by this path.  One body
+                // per light kind, with nothing merged between them (a value that is uniform in one and per lane in the other would become a
+                // vector register in both).
+                typedef const __attribute__((address_space(4))) LightK *ConstLights;
+                ConstLights clight = (ConstLights) (glight + fa.n_lights);
+                const Ball *my_ball = sball + wave;
+                const BoxH *my_box = sbox + wave;
+#define RT_LOAD_LIGHTK(lk, l) /* member by member: every one a scalar load from the constant address space, issued together */ \
+                    LightK lk; \
+                    lk.p[0] = clight[l].p[0]; lk.p[1] = clight[l].p[1]; lk.p[2] = clight[l].p[2]; \
+                    lk.sdir[0] = clight[l].sdir[0]; lk.sdir[1] = clight[l].sdir[1]; lk.sdir[2] = clight[l].sdir[2]; \
+                    lk.u2 = clight[l].u2; lk.inv_uu = clight[l].inv_uu; lk.len_u = clight[l].len_u; lk.four_u2 = clight[l].four_u2; \
+                    lk.s_yz = clight[l].s_yz; lk.s_xz = clight[l].s_xz; lk.s_xy = clight[l].s_xy; \
+                    lk.color[0] = clight[l].color[0]; lk.color[1] = clight[l].color[1]; lk.color[2] = clight[l].color[2]; \
+                    lk.flags = clight[l].flags;
+                // Point lights first, shadow tests only: one bit per (lane, point light) in a register.  Their culling test is the widest
+                // stretch of this kernel in registers; in a pass of its own it does not meet the colour accumulators and constants of
+                // the ordered pass below, which only reads the bit when the light's turn comes (include/light_impl.h:19-21: (light -
+                // point) through FP32, max_t = 1).
+                const unsigned long long pt_mask = ((unsigned long long) fa.pt_mask[1] << 32) | fa.pt_mask[0];
+                unsigned long long pt_blocked = 0ull; // bit l: point light l is blocked for this lane's hit
+                for (unsigned long long pm = pt_mask; pm != 0ull; pm &= pm - 1ull) { // wave-uniform
+                    const uint32_t l = (uint32_t) __builtin_ctzll(pm);
+                    RT_LOAD_LIGHTK(lk, l)
+                    const D3 spl{hp[tid], hp[WG + tid], hp[2 * WG + tid]};
+                    const double dx = lk.p[0] - spl.x, dy = lk.p[1] - spl.y, dz = lk.p[2] - spl.z;
+                    const double q = dot3(sn, D3{dx, dy, dz});
+                    const double mag = fabs(sn.x * dx) + fabs(sn.y * dy) + fabs(sn.z * dz);
+                    const bool wanted = hit && !(q < -1e-9 * mag); // behind the surface by a margin 10^7 times the rounding: the term is +0 (as in the other path)
+                    if (COUNT || __any(wanted)) {
+                        Mono sd;
+                        sd.o = sm.o; sd.u0 = sm.u0;
+                        mono_set_d<false>(sd, D3{(double) (float) dx, (double) (float) dy, (double) (float) dz});
+                        mono_set_od<false>(sd);
+                        if (wanted) cnt.traced();
+                        const int blocker = shadow_blocker<COUNT, false, false, true, true>(fa, S, gobj, sd, 1.0, COUNT ? hit : wanted, wanted, my_ball, my_box, my_crec, lk, lane, cnt);
+                        if (hit) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
+                        if (hit && blocker != NO_BLOCKER) pt_blocked |= 1ull << l;
+                    } else if (COUNT && hit) {
+                        cnt.add(3, fa.n_obj);
+                    }
+                }
+                // ---- lights in order (src/update-cpu.cpp:62-77) ----
                 const MatEntry mt = S.mat[bi];
                 const F3 aop{mt.albedo[0] / PI_F, mt.albedo[1] / PI_F, mt.albedo[2] / PI_F}; // object_color / pi, once per hit
                 F3 acc{0.0f, 0.0f, 0.0f};
-                const CullRec *my_crec = reinterpret_cast<const CullRec *>(smem + (L.crec + wave * L.n_crec * (uint32_t) sizeof(CullRec)));
-                // (the lights through the constant address space: scalar loads, their fields in SGPRs -- no vector register holds a
-                // per-light constant.  The LDS copy of the lights is not used by this path.)
-                typedef const __attribute__((address_space(4))) DevLight *ConstLights;
-                ConstLights clight = (ConstLights) glight;
                 for (uint32_t l = 0; l < fa.n_lights; l++) {
-                    const auto &lt = clight[l];
-                    const bool lt_spherical = lt.spherical != 0;
-                    const bool lt_backface_exact = lt.backface_exact != 0;
+                    RT_LOAD_LIGHTK(lk, l)
                     if (hit) cnt.add(1);
-                    bool wanted = hit; // the lanes the product build traces (see the same place in the other path)
-                    bool own_skip = false;
-                    unsigned long long own_excl = 0ull;
-                    if (lt_backface_exact) { // directional, all colours finite: a light behind the surface adds exactly +0, shadowed or not
-                        const float lam = (float) dot3(sn, D3{lt.p[0], lt.p[1], lt.p[2]});
-                        wanted = hit && (0.0f < lam);
-                        if (!COUNT && !__any(wanted)) continue;
-                        own_skip = wanted && skip_geom;
-                        own_excl = COUNT ? 0ull : own_all;
-                    }
-                    double max_t;
-                    if (lt_spherical) {
-                        max_t = 1.0; // shadow_ray, include/light_impl.h:19-21: (light - point) through FP32
-                        const D3 sp{hp[tid], hp[WG + tid], hp[2 * WG + tid]};
-                        const double dx = lt.p[0] - sp.x, dy = lt.p[1] - sp.y, dz = lt.p[2] - sp.z;
-                        const double q = dot3(sn, D3{dx, dy, dz});
-                        const double mag = fabs(sn.x * dx) + fabs(sn.y * dy) + fabs(sn.z * dz);
-                        wanted = hit && !(q < -1e-9 * mag); // behind the surface by a margin 10^7 times the rounding: the term is +0 (as in the other path)
-                        if (!COUNT && !__any(wanted)) continue;
-                        const D3 sd{(double) (float) dx, (double) (float) dy, (double) (float) dz};
-                        mono_set_d<false>(sm, sd);
-                    } else {
-                        max_t = 1e6; // include/light_impl.h:23-25: the per-light constant direction and its monomials
-                        sm.d = D3{lt.sdir[0], lt.sdir[1], lt.sdir[2]};
-                        sm.dxx = lt.dxx; sm.dyy = lt.dyy; sm.dzz = lt.dzz;
-                        sm.u2 = lt.u2;
-                    }
-                    mono_set_od<false>(sm);
-                    if (wanted) cnt.traced();
-                    int blocker;
-                    if (lt_spherical) {
-                        blocker = shadow_blocker<COUNT, false, false, true, true>(fa, S, gobj, sm, max_t, COUNT ? hit : wanted, wanted, sball + wave, sbox + wave, my_crec, lt, lane, cnt);
-                    } else {
-                        // (|d|^2 <= EPS: the reference takes its linear branch, to which the own-sphere argument does not apply)
-                        const bool quad_l = __builtin_amdgcn_readfirstlane((int) (fabs(sm.u2) > EPS)) != 0;
-                        blocker = shadow_blocker<COUNT, false, false, false, true>(fa, S, gobj, sm, max_t, COUNT ? hit : wanted, wanted, sball + wave, sbox + wave, my_crec, lt, lane,
-                                                                                   cnt, bi, own_skip && quad_l, quad_l ? own_excl : 0ull);
-                    }
-                    if (hit) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
-                    if (hit && blocker == NO_BLOCKER && (wanted || !lt_backface_exact)) {
-                        const double lp[3] = {lt.p[0], lt.p[1], lt.p[2]};
-                        const float lc[3] = {lt.color[0], lt.color[1], lt.color[2]};
-                        D3 spl{0.0, 0.0, 0.0};
-                        if (lt_spherical) spl = D3{hp[tid], hp[WG + tid], hp[2 * WG + tid]};
-                        const F3 col = surface_color_pre(lp, lc, lt_spherical, spl, sn, aop);
+                    if (!((pt_mask >> l) & 1ull)) { // ---- directional: include/light_impl.h:23-25, one direction for every ray ----
+                        const bool bfe = (lk.flags & 2u) != 0u;
+                        const float lam = (float) dot3(sn, D3{lk.p[0], lk.p[1], lk.p[2]}); // surface_color's (float) dot(n, dir), include/light_impl.h:42
+                        // a light behind the surface adds exactly +0 (all colours finite: bfe), shadowed or not: such lanes sit the light out
+                        const bool wanted = hit && (!bfe || 0.0f < lam);
+                        if (COUNT || __any(wanted)) {
+                            const bool quad_l = (lk.flags & 4u) != 0u; // (|d|^2 <= EPS: the reference takes its linear branch, to which the own-sphere argument does not apply)
+                            Mono sd;
+                            sd.o = sm.o; sd.u0 = sm.u0;
+                            sd.d = D3{lk.sdir[0], lk.sdir[1], lk.sdir[2]};
+                            sd.u2 = lk.u2;
+                            mono_set_od<false>(sd);
+                            if (wanted) cnt.traced();
+                            const int blocker = shadow_blocker<COUNT, false, false, false, true>(fa, S, gobj, sd, 1e6, COUNT ? hit : wanted, wanted, my_ball, my_box, my_crec, lk, lane, cnt, bi,
+                                                                                                 bfe && quad_l && wanted && skip_geom, (!COUNT && bfe && quad_l) ? own_all : 0ull);
+                            if (hit) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
+                            if (wanted && blocker == NO_BLOCKER) { // ((albedo / pi) * colour) * max(0, n.l), left to right (include/light_impl.h:43)
+                                const float mx = (0.0f < lam) ? lam : 0.0f;
+                                cnt.shaded();
+                                acc.x += aop.x * lk.color[0] * mx;
+                                acc.y += aop.y * lk.color[1] * mx;
+                                acc.z += aop.z * lk.color[2] * mx;
+                            }
+                        }
+                    } else if (hit && !((pt_blocked >> l) & 1ull)) { // ---- point light, not blocked (lanes that sat its test out add their +0 like the other path does) ----
+                        const D3 spl{hp[tid], hp[WG + tid], hp[2 * WG + tid]};
+                        const double lp[3] = {lk.p[0], lk.p[1], lk.p[2]};
+                        const float lc[3] = {lk.color[0], lk.color[1], lk.color[2]};
+                        const F3 col = surface_color_pre(lp, lc, true, spl, sn, aop);
                         cnt.shaded();
                         acc.x += col.x;
                         acc.y += col.y;
                         acc.z += col.z;
                     }
                 }
+#undef RT_LOAD_LIGHTK
                 if (hit) { // glm::min(vec3(1.0f), acc), src/update-cpu.cpp:77
                     res.x = (acc.x < 1.0f) ? acc.x : 1.0f;
                     res.y = (acc.y < 1.0f) ? acc.y : 1.0f;

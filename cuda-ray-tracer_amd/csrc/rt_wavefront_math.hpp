@@ -323,13 +323,19 @@ __device__ __forceinline__ bool crec_relevant(const CullRec &c, const D3 &sdir, 
 // |sdir x e_k| is bounded by the 1-norm of its two components (no square root; the bound only has to be conservative).
 // reach = limr carries the same margins as the ball test (1e-6 of the distances involved), which dwarf the rounding of the
 // two-term products here.  NaN / inf reach: every comparison is false, the sphere stays.
+// (s_yz = |sdir.y| + |sdir.z| etc.: per-light constants, formed by the caller or taken from the light table)
+__device__ __forceinline__ bool crec_in_box_shadow(const CullRec &c, const BoxH &h, const D3 &sdir, double s_yz, double s_xz, double s_xy)
+{
+    const double ax = fabs(sdir.x), ay = fabs(sdir.y), az = fabs(sdir.z);
+    const double px = c.wy * sdir.z - c.wz * sdir.y, bx = (h.hy * az + h.hz * ay) + c.limr * s_yz;
+    const double py = c.wz * sdir.x - c.wx * sdir.z, by = (h.hz * ax + h.hx * az) + c.limr * s_xz;
+    const double pz = c.wx * sdir.y - c.wy * sdir.x, bz = (h.hx * ay + h.hy * ax) + c.limr * s_xy;
+    return !(fabs(px) > bx * (1.0 + 1e-9)) && !(fabs(py) > by * (1.0 + 1e-9)) && !(fabs(pz) > bz * (1.0 + 1e-9));
+}
 __device__ __forceinline__ bool crec_in_box_shadow(const CullRec &c, const BoxH &h, const D3 &sdir)
 {
     const double ax = fabs(sdir.x), ay = fabs(sdir.y), az = fabs(sdir.z);
-    const double px = c.wy * sdir.z - c.wz * sdir.y, bx = (h.hy * az + h.hz * ay) + c.limr * (ay + az);
-    const double py = c.wz * sdir.x - c.wx * sdir.z, by = (h.hz * ax + h.hx * az) + c.limr * (ax + az);
-    const double pz = c.wx * sdir.y - c.wy * sdir.x, bz = (h.hx * ay + h.hy * ax) + c.limr * (ax + ay);
-    return !(fabs(px) > bx * (1.0 + 1e-9)) && !(fabs(py) > by * (1.0 + 1e-9)) && !(fabs(pz) > bz * (1.0 + 1e-9));
+    return crec_in_box_shadow(c, h, sdir, ay + az, ax + az, ax + ay);
 }
 
 __device__ __forceinline__ void blend(F3 &res, float ratio, const F3 &c)

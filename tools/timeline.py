@@ -88,6 +88,30 @@ nw = np.array([int((traced & (cu == c)).sum()) for c in cus])
 last = np.array([end[traced & (cu == c)].max() for c in cus])
 print(f"{len(cus)} CUs ran tracing waves: waves per CU min {nw.min()} median {int(np.median(nw))} max {nw.max()}; shadow-phase wave-us per CU min {work.min():.0f} median {np.median(work):.0f} max {work.max():.0f};"
       f" last tracing wave ends: min {last.min():.1f} median {np.median(last):.1f} max {last.max():.1f} us; correlation(work, end) {np.corrcoef(work, last)[0, 1]:.2f}")
+# How well could the shadow-phase work be spread?  Per-SIMD sums of the tracing waves' shadow-phase cycles as they ran (HW_ID simd_id [5:4]),
+# against longest-first assignments of the same waves / of whole workgroups to 1024 SIMDs / 256 CUs (the measured cycles include the
+# slow-down of a crowded SIMD, so this is indicative only).
+blocks = row_index // 4
+simd = ((hwid >> np.uint64(4)) & np.uint64(3)).astype(np.int64)
+key = cu[traced] * 4 + simd[traced]
+bw = rows[traced, 6].astype(np.float64) / 2400.0
+loads = {}
+for k, v in zip(key, bw):
+    loads[int(k)] = loads.get(int(k), 0.0) + v
+ld = np.array(list(loads.values()) + [0.0] * max(0, 1024 - len(loads)))
+def lpt(items, bins):
+    import heapq
+    h = [0.0] * bins
+    heapq.heapify(h)
+    for v in sorted(items, reverse=True):
+        heapq.heappush(h, heapq.heappop(h) + v)
+    return max(h)
+wg_b = {}
+for b, v in zip(blocks[traced], bw):
+    wg_b[int(b)] = wg_b.get(int(b), 0.0) + v
+print(f"shadow-phase wave-us per SIMD as run: mean {bw.sum() / 1024:.1f} max {ld.max():.1f} (max / mean {ld.max() / (bw.sum() / 1024):.2f}); "
+      f"longest-first by wave over 1024 SIMDs: max {lpt(bw, 1024):.1f}; by workgroup over 256 CUs (per SIMD): max {lpt(wg_b.values(), 256) / 4:.1f}; "
+      f"largest single wave {bw.max():.1f}, largest workgroup / 4 {max(wg_b.values()) / 4:.1f}")
 # which workgroups (in dispatch order) landed on which CU?
 blocks = row_index // 4
 for c in cus[:6]:

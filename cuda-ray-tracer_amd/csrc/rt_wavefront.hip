@@ -61,6 +61,18 @@ namespace RT_SYM(rtw) {
 
 using namespace rtm;
 
+// One light out of the LightK table (rt_scene_dev.h) through the constant address space: member by member, every one a scalar
+// load, issued together -- a directional light's constants then live in SGPRs.  `clight` must be in scope.
+#define RT_LOAD_LIGHTK(lk, l) \
+    LightK lk; \
+    lk.p[0] = clight[l].p[0]; lk.p[1] = clight[l].p[1]; lk.p[2] = clight[l].p[2]; \
+    lk.sdir[0] = clight[l].sdir[0]; lk.sdir[1] = clight[l].sdir[1]; lk.sdir[2] = clight[l].sdir[2]; \
+    lk.u2 = clight[l].u2; lk.inv_uu = clight[l].inv_uu; lk.len_u = clight[l].len_u; lk.four_u2 = clight[l].four_u2; \
+    lk.s_yz = clight[l].s_yz; lk.s_xz = clight[l].s_xz; lk.s_xy = clight[l].s_xy; \
+    lk.color[0] = clight[l].color[0]; lk.color[1] = clight[l].color[1]; lk.color[2] = clight[l].color[2]; \
+    lk.flags = clight[l].flags;
+typedef const __attribute__((address_space(4))) LightK *ConstLights;
+
 constexpr uint32_t WG = 256; // threads per workgroup = pixels per tile
 
 // Pixel of thread `tid` inside its 16x16 tile: wave w owns the 8x8 quadrant (w & 1, w >> 1), lane l the pixel (l & 7, l >> 3)
@@ -623,7 +635,7 @@ struct LdsLayout {
         if (shadow_words == 0) shadow_words = 1;
         uint32_t off = 0;
         scene = off; off = align16(off + scene_bytes);
-        light = off; off = align16(off + (lean ? 0u : n_lights * (uint32_t) sizeof(DevLight))); // (the lean path reads the lights through scalar loads)
+        light = off; // (no LDS copy of the lights any more: every path reads them through scalar loads, LightK)
         hp = off; off = align16(off + 3 * WG * 8); // (the lean path parks the hit point of each pixel here across the light loop: point lights only read it)
         hn = off; off = align16(off + 3 * Q * 8);
         hdir = off; off = align16(off + (has_mirror ? 3 * WG * 8 : 0)); // mirrors only: the pixel's incoming direction ...
@@ -631,7 +643,7 @@ struct LdsLayout {
         hidx = off; off = align16(off + Q * 4); // (object << 8) | owner lane
         hpix = hidx;
         color = off; off = align16(off + 3 * Q * 4);
-        shadow = off; off = align16(off + Q * shadow_words * 4);
+        shadow = off; off = align16(off + (lean ? 0u : 4u * (n_lights ? n_lights : 1u) * 8u)); // one 64-bit mask per (chunk, light): hits that skip the light when shading
         ball = off; off = align16(off + 4 * (uint32_t) sizeof(Ball));
         box = off; off = align16(off + 4 * (uint32_t) sizeof(BoxH));
         crec = off; off = align16(off + 4 * n_crec * (uint32_t) sizeof(CullRec));
@@ -664,7 +676,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
     for (uint32_t base = 0; base < fa.n_us; base += 64) {
         const uint32_t end = (base + 64 < fa.n_us) ? base + 64 : fa.n_us;
         unsigned long long cand = 0;
-        if (OWN || fa.cull) {
+        if (fa.cull) {
             unsigned long long it;
             if (!SPHERICAL && base == 0) {
                 it = relevant_mask_directional(crec, end, sm.d, lt.inv_uu, lt.len_u, lane); // sm.d is this light's FP32-rounded direction
@@ -867,6 +879,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     void *__restrict__ fb = cold.fb;
     unsigned long long *__restrict__ counters = cold.counters;
     const double *__restrict__ camx = cold.camx, *__restrict__ camy = cold.camy;
+    ConstLights clight = (ConstLights) (glight + fa.n_lights); // the LightK table behind the DevLight array (rt_create)
+    constexpr bool OWNG = !HAS_GQ && !HAS_CUBIC; // instantiations whose scenes may consist of unit spheres only: the own-sphere rule applies there
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool NEED_CROSS = HAS_GQ || HAS_CUBIC;
     static_assert(!LEAN || (!HAS_GQ && !HAS_CUBIC && !HAS_MIRROR), "the lean path renders unit spheres only");
@@ -892,7 +906,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     uint32_t *hidx = reinterpret_cast<uint32_t *>(smem + L.hidx); // (object of hit h << 8) | its owner lane (pixel)
     float *scolor = reinterpret_cast<float *>(smem + L.color);    // [3][WG] direct lighting of the pixel's hit this round
     float *spark = reinterpret_cast<float *>(smem + L.park);      // [5][WG] mirrors: running colour, blend ratio, depth of the pixel
-    uint32_t *sshadow = reinterpret_cast<uint32_t *>(smem + L.shadow); // [WG][shadow_words] bit l: light l is blocked
+    unsigned long long *sblk = reinterpret_cast<unsigned long long *>(smem + L.shadow); // [4 chunks][n_lights] bit i: hit i of the chunk skips the light when shading (blocked, or the light is behind it)
     Ball *sball = reinterpret_cast<Ball *>(smem + L.ball);
     BoxH *sbox = reinterpret_cast<BoxH *>(smem + L.box);
     CullRec *screc = reinterpret_cast<CullRec *>(smem + L.crec); // [4 chunks][L.n_crec]
@@ -1136,7 +1150,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         // camera-table reads.  Two 16-byte pieces per thread cover 8 KB of tables + lights; larger scenes copy the rest the ordinary way.
         const uint4 *stage_scene = reinterpret_cast<const uint4 *>(gscene + fa.off_us);
         const uint4 *stage_light = reinterpret_cast<const uint4 *>(glight);
-        const uint32_t n16 = fa.stage_bytes / 16, tot16 = n16 + (LEAN ? 0u : fa.n_lights * (uint32_t) (sizeof(DevLight) / 16));
+        const uint32_t n16 = fa.stage_bytes / 16, tot16 = n16; // (the class tables and materials; the lights are read through scalar loads)
         uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = make_uint4(0, 0, 0, 0);
         if (tid < tot16) pre0 = tid < n16 ? stage_scene[tid] : stage_light[tid - n16];
         if (tid + WG < tot16) pre1 = tid + WG < n16 ? stage_scene[tid + WG] : stage_light[tid + WG - n16];
@@ -1248,18 +1262,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 // SGPRs -- no vector register holds a per-light constant; the LDS copy of the lights is not used by this path.  One body
                 // per light kind, with nothing merged between them (a value that is uniform in one and per lane in the other would become a
                 // vector register in both).
-                typedef const __attribute__((address_space(4))) LightK *ConstLights;
-                ConstLights clight = (ConstLights) (glight + fa.n_lights);
                 const Ball *my_ball = sball + wave;
                 const BoxH *my_box = sbox + wave;
-#define RT_LOAD_LIGHTK(lk, l) /* member by member: every one a scalar load from the constant address space, issued together */ \
-                    LightK lk; \
-                    lk.p[0] = clight[l].p[0]; lk.p[1] = clight[l].p[1]; lk.p[2] = clight[l].p[2]; \
-                    lk.sdir[0] = clight[l].sdir[0]; lk.sdir[1] = clight[l].sdir[1]; lk.sdir[2] = clight[l].sdir[2]; \
-                    lk.u2 = clight[l].u2; lk.inv_uu = clight[l].inv_uu; lk.len_u = clight[l].len_u; lk.four_u2 = clight[l].four_u2; \
-                    lk.s_yz = clight[l].s_yz; lk.s_xz = clight[l].s_xz; lk.s_xy = clight[l].s_xy; \
-                    lk.color[0] = clight[l].color[0]; lk.color[1] = clight[l].color[1]; lk.color[2] = clight[l].color[2]; \
-                    lk.flags = clight[l].flags;
                 // Point lights first, shadow tests only: one bit per (lane, point light) in a register.  Their culling test is the widest
                 // stretch of this kernel in registers; in a pass of its own it does not meet the colour accumulators and constants of
                 // the ordered pass below, which only reads the bit when the light's turn comes (include/light_impl.h:19-21: (light -
@@ -1329,7 +1333,6 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                         acc.z += col.z;
                     }
                 }
-#undef RT_LOAD_LIGHTK
                 if (hit) { // glm::min(vec3(1.0f), acc), src/update-cpu.cpp:77
                     res.x = (acc.x < 1.0f) ? acc.x : 1.0f;
                     res.y = (acc.y < 1.0f) ? acc.y : 1.0f;
@@ -1388,11 +1391,16 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 live = false;
             }
             D3 sp{0.0, 0.0, 0.0}, sn{0.0, 0.0, 1.0};
+            uint32_t own_ok = 0u; // bit 31 of the hit's queue word (below)
             if (hit) {
                 sp = D3{o.x + best_t * dir.x, o.y + best_t * dir.y, o.z + best_t * dir.z};
                 if (ALL_SPHERES_POSSIBLE && fa.n_us == fa.n_obj) { // launch-uniform: every object is a unit sphere -- table index == object index
-                    if (staged) sn = sphere_normal(S.us[best], sp);  // three coefficients from the table instead of twenty from the object record
-                    else sn = sphere_normal(G.us[best], sp);
+                    const UsEntry eo = staged ? S.us[best] : G.us[best]; // three coefficients from the table instead of twenty from the object record
+                    sn = sphere_normal(eo, sp);
+                    Mono mo;
+                    mono_set_o<false>(mo, D3{sp.x + SHADOW_BIAS * sn.x, sp.y + SHADOW_BIAS * sn.y, sp.z + SHADOW_BIAS * sn.z});
+                    const double t0_own = us_t0(eo, mo); // the reference's own t0 of this hit's shadow rays against the sphere it lies on
+                    own_ok = (t0_own > (double) eo.own_lo && t0_own < (double) eo.own_hi) ? 0x80000000u : 0u;
                 } else {
                     sn = normal_vector(gobj[best].c, sp); // 20 coefficients of the hit object, gathered from global (L2) per hit
                 }
@@ -1435,7 +1443,10 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 my_slot = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u) + (uint32_t) __popcll(hm & ((1ull << lane) - 1ull));
                 hp[my_slot] = sp.x; hp[WG + my_slot] = sp.y; hp[2 * WG + my_slot] = sp.z;
                 hn[my_slot] = sn.x; hn[WG + my_slot] = sn.y; hn[2 * WG + my_slot] = sn.z;
-                hidx[my_slot] = ((uint32_t) best << 8) | tid; // object of hit h, its owner lane (pixel) in the low byte
+                // object of hit h, its owner lane (pixel) in the low byte; bit 31: scenes of unit spheres only -- the reference's own t0 of this
+                // hit's shadow rays against the sphere it lies on is inside that sphere's window (own_sphere_skippable in the lean path has
+                // the argument: such a ray towards a directional light in front of the surface is not tested against that sphere)
+                hidx[my_slot] = own_ok | ((uint32_t) best << 8) | tid;
                 if (HAS_MIRROR) { // the bounce needs the incoming direction again in phase D; keep it out of registers meanwhile
                     hdir[tid] = dir.x; hdir[WG + tid] = dir.y; hdir[2 * WG + tid] = dir.z;
                 }
@@ -1445,8 +1456,6 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 spark[3 * WG + tid] = cur_ratio;
                 reinterpret_cast<uint32_t *>(spark)[4 * WG + tid] = n_refl;
             }
-            if (tid < n_hits)
-                for (uint32_t w = 0; w < L.shadow_words; w++) sshadow[tid * L.shadow_words + w] = 0;
             if (first && tid == 0) s_cost[0] = 0;
             lds_barrier();
 
@@ -1495,62 +1504,69 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]};
                     mono_set_o<NEED_CROSS>(sm, D3{p.x + SHADOW_BIAS * nrm.x, p.y + SHADOW_BIAS * nrm.y, p.z + SHADOW_BIAS * nrm.z});
                 }
+                // this hit's own sphere and its window bit (scenes of unit spheres only; see the queue)
+                const uint32_t hinfo_b = hidx[hs];
+                const uint32_t own = (hinfo_b >> 8) & 0x7FFFFFu;
+                const bool own_ok = OWNG && valid && (hinfo_b >> 31) != 0u && fa.n_us == fa.n_obj;
+                const CullRec *my_crec = reinterpret_cast<const CullRec *>(smem + (L.crec + c * L.n_crec * (uint32_t) sizeof(CullRec)));
                 for (uint32_t l = (wave + 4u - (c & 3u)) & 3u; l < fa.n_lights; l += 4) {
-                    const DevLight &lt = S.light[l]; // wave-uniform LDS reads
-                    // (the two flags through readfirstlane: values read from LDS are not known to be uniform, and the branches on them
-                    // would be compiled as divergent ones)
-                    const bool lt_spherical = __builtin_amdgcn_readfirstlane((int) lt.spherical) != 0;
-                    const bool lt_backface_exact = __builtin_amdgcn_readfirstlane((int) lt.backface_exact) != 0;
+                    // the light through the constant address space (LightK, rt_scene_dev.h): scalar loads, its fields in SGPRs; one body per
+                    // light kind, nothing merged between them
+                    RT_LOAD_LIGHTK(lk, l)
                     if (valid) cnt.add(1);
-                    // A directional light behind the surface contributes exactly +0 whether or not it is shadowed:
-                    // surface_color multiplies by max(0.0f, (float) dot(n, light.p)) (include/light_impl.h:43), and the
-                    // colour it scales is finite (checked at rt_create).  Such lanes sit the shadow test out, and a light that is behind EVERY
-                    // hit of the chunk costs nothing beyond this dot product.  (COUNT builds test them anyway: the
-                    // reference-equivalent test count needs the index of the first blocker.)
-                    bool wanted = valid; // the lanes the product build traces; a counting build traces every hit's ray (it needs the first blocker's index)
-                    if (lt_backface_exact) { // directional, all colours finite (rt_scene_dev.h)
-                        const float lam = (float) dot3(nrm, D3{lt.p[0], lt.p[1], lt.p[2]});
-                        wanted = valid && (0.0f < lam);
-                        // ... and the shading phase need not look at this light for these hits either: same bit as "blocked"
-                        if (!COUNT && valid && !wanted) atomicOr(&sshadow[h * L.shadow_words + (l >> 5)], 1u << (l & 31));
-                        if (!COUNT && !__any(wanted)) continue;
-                    }
-                    double max_t;
-                    if (lt_spherical) {
-                        // shadow_ray, include/light_impl.h:19-21: (light - point) through FP32
-                        max_t = 1.0;
-                        const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]}; // re-read: not kept in registers across lights
-                        {
-                            // Same argument for a point light behind the surface: the shading term is
-                            // max(0, (float) dot(n, normalize(l - p))) (include/light_impl.h:38-43), normalisation scales by
-                            // a positive factor, so the sign is that of q = dot(n, l - p) unless q is lost in rounding --
-                            // lanes sit out only when q < 0 by a margin 10^7 times the rounding error of either form.
-                            const double dx = lt.p[0] - p.x, dy = lt.p[1] - p.y, dz = lt.p[2] - p.z;
-                            const double q = dot3(nrm, D3{dx, dy, dz});
-                            const double mag = fabs(nrm.x * dx) + fabs(nrm.y * dy) + fabs(nrm.z * dz);
-                            wanted = valid && !(q < -1e-9 * mag);
-                            if (!COUNT && !__any(wanted)) continue;
+                    unsigned long long skip; // hits of the chunk that skip this light when shading
+                    if (!(lk.flags & 1u)) { // ---- directional: include/light_impl.h:23-25 ----
+                        // A directional light behind the surface contributes exactly +0 whether or not it is shadowed:
+                        // surface_color multiplies by max(0.0f, (float) dot(n, light.p)) (include/light_impl.h:43), and the
+                        // colour it scales is finite (checked at rt_create: flag 2).  Such lanes sit the shadow test out AND the shading of this
+                        // light.  (COUNT builds test them anyway: the reference-equivalent test count needs the index of the first blocker.)
+                        const bool bfe = (lk.flags & 2u) != 0u;
+                        const float lam = (float) dot3(nrm, D3{lk.p[0], lk.p[1], lk.p[2]});
+                        const bool wanted = valid && (!bfe || 0.0f < lam); // the lanes the product build traces
+                        skip = COUNT ? 0ull : __ballot(valid && !wanted);
+                        if (COUNT || __any(wanted)) {
+                            const bool quad_l = (lk.flags & 4u) != 0u;
+                            Mono sd = sm;
+                            if (NEED_CROSS) {
+                                mono_set_d<true>(sd, D3{lk.sdir[0], lk.sdir[1], lk.sdir[2]});
+                            } else {
+                                sd.d = D3{lk.sdir[0], lk.sdir[1], lk.sdir[2]};
+                                sd.u2 = lk.u2;
+                            }
+                            mono_set_od<NEED_CROSS>(sd);
+                            if (wanted) cnt.traced();
+                            const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, false, OWNG>(fa, S, gobj, sd, 1e6, COUNT ? valid : wanted, wanted, sball + c, sbox + c, my_crec, lk, lane, cnt,
+                                                                                                      own, own_ok && bfe && quad_l && wanted, 0ull);
+                            // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
+                            if (valid) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
+                            skip |= __ballot(valid && blocker != NO_BLOCKER);
+                        } else if (COUNT && valid) {
+                            cnt.add(3, fa.n_obj);
                         }
-                        const D3 sd{(double) (float) (lt.p[0] - p.x), (double) (float) (lt.p[1] - p.y), (double) (float) (lt.p[2] - p.z)};
-                        mono_set_d<NEED_CROSS>(sm, sd);
-                    } else {
-                        // include/light_impl.h:23-25: the per-light constant direction and its monomials
-                        max_t = 1e6;
-                        sm.d = D3{lt.sdir[0], lt.sdir[1], lt.sdir[2]};
-                        sm.dxx = lt.dxx; sm.dyy = lt.dyy; sm.dzz = lt.dzz;
-                        if (NEED_CROSS) { sm.dxy = lt.dxy; sm.dxz = lt.dxz; sm.dyz = lt.dyz; }
-                        sm.u2 = lt.u2;
+                    } else { // ---- point light: include/light_impl.h:19-21, (light - point) through FP32 ----
+                        const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]}; // re-read: not kept in registers across lights
+                        // Same argument for a point light behind the surface: the shading term is max(0, (float) dot(n, normalize(l - p)))
+                        // (include/light_impl.h:38-43), normalisation scales by a positive factor, so the sign is that of q = dot(n, l - p)
+                        // unless q is lost in rounding -- lanes sit the TEST out only when q < 0 by a margin 10^7 times the rounding error of
+                        // either form (their term is then shaded as +0).
+                        const double dx = lk.p[0] - p.x, dy = lk.p[1] - p.y, dz = lk.p[2] - p.z;
+                        const double q = dot3(nrm, D3{dx, dy, dz});
+                        const double mag = fabs(nrm.x * dx) + fabs(nrm.y * dy) + fabs(nrm.z * dz);
+                        const bool wanted = valid && !(q < -1e-9 * mag);
+                        skip = 0ull;
+                        if (COUNT || __any(wanted)) {
+                            Mono sd = sm;
+                            mono_set_d<NEED_CROSS>(sd, D3{(double) (float) dx, (double) (float) dy, (double) (float) dz});
+                            mono_set_od<NEED_CROSS>(sd);
+                            if (wanted) cnt.traced();
+                            const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, true, OWNG>(fa, S, gobj, sd, 1.0, COUNT ? valid : wanted, wanted, sball + c, sbox + c, my_crec, lk, lane, cnt);
+                            if (valid) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
+                            skip = __ballot(valid && blocker != NO_BLOCKER);
+                        } else if (COUNT && valid) {
+                            cnt.add(3, fa.n_obj);
+                        }
                     }
-                    mono_set_od<NEED_CROSS>(sm);
-                    if (wanted) cnt.traced();
-                    const int blocker = lt_spherical
-                        ? shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, true>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, sbox + c, reinterpret_cast<const CullRec *>(smem + (L.crec + c * L.n_crec * (uint32_t) sizeof(CullRec))), lt, lane, cnt)
-                        : shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, false>(fa, S, gobj, sm, max_t, COUNT ? valid : wanted, wanted, sball + c, sbox + c, reinterpret_cast<const CullRec *>(smem + (L.crec + c * L.n_crec * (uint32_t) sizeof(CullRec))), lt, lane, cnt);
-                    if (valid) {
-                        // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
-                        cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
-                        if (blocker != NO_BLOCKER) atomicOr(&sshadow[h * L.shadow_words + (l >> 5)], 1u << (l & 31));
-                    }
+                    if (lane == 0) sblk[c * fa.n_lights + l] = skip;
                 }
             }
             if (first && listing && lane == 0) atomicMax(&s_cost[0], (uint32_t) ((__builtin_amdgcn_s_memtime() - b_t0) >> 6) + 1u);
@@ -1572,29 +1588,45 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             }
 
             // ---------------- phase C: shade each hit, lights in order ----------------
-            if (tid < n_hits) {
+            // (hit h is lane h & 63 of wave h >> 6: a wave shades the chunk with its own number, and a light's mask is one broadcast read)
+            if (wave < n_chunks) { // wave-uniform
                 const uint32_t h = tid;
-                const D3 p{hp[h], hp[WG + h], hp[2 * WG + h]};
-                const D3 n{hn[h], hn[WG + h], hn[2 * WG + h]};
-                const uint32_t hinfo = hidx[h];
-                const MatEntry mt = S.mat[hinfo >> 8];
+                const bool v = h < n_hits;
+                const uint32_t hs = v ? h : wave * 64u;
+                const D3 n{hn[hs], hn[WG + hs], hn[2 * WG + hs]};
+                const uint32_t hinfo = hidx[hs];
+                const MatEntry mt = S.mat[(hinfo >> 8) & 0x7FFFFFu];
                 const F3 aop{mt.albedo[0] / PI_F, mt.albedo[1] / PI_F, mt.albedo[2] / PI_F}; // object_color / pi, once per hit
                 F3 acc{0.0f, 0.0f, 0.0f};
                 for (uint32_t l = 0; l < fa.n_lights; l++) {
-                    const bool blocked = (sshadow[h * L.shadow_words + (l >> 5)] >> (l & 31)) & 1u;
-                    if (!blocked) {
-                        const DevLight &lt = S.light[l];
-                        F3 col = surface_color_pre(lt.p, lt.color, lt.spherical != 0, p, n, aop);
+                    RT_LOAD_LIGHTK(lk, l)
+                    const bool lit = v && !((sblk[wave * fa.n_lights + l] >> lane) & 1ull);
+                    if (!(lk.flags & 1u)) { // directional: ((albedo / pi) * colour) * max(0, n.l), left to right (include/light_impl.h:43)
+                        if (lit) {
+                            const float lam = (float) dot3(n, D3{lk.p[0], lk.p[1], lk.p[2]});
+                            const float mx = (0.0f < lam) ? lam : 0.0f;
+                            cnt.shaded();
+                            acc.x += aop.x * lk.color[0] * mx;
+                            acc.y += aop.y * lk.color[1] * mx;
+                            acc.z += aop.z * lk.color[2] * mx;
+                        }
+                    } else if (lit) {
+                        const D3 p{hp[hs], hp[WG + hs], hp[2 * WG + hs]};
+                        const double lp[3] = {lk.p[0], lk.p[1], lk.p[2]};
+                        const float lc[3] = {lk.color[0], lk.color[1], lk.color[2]};
+                        const F3 col = surface_color_pre(lp, lc, true, p, n, aop);
                         cnt.shaded();
                         acc.x += col.x;
                         acc.y += col.y;
                         acc.z += col.z;
                     }
                 }
-                const uint32_t px = hinfo & 255u;
-                scolor[px] = (acc.x < 1.0f) ? acc.x : 1.0f; // glm::min(vec3(1.0f), acc)
-                scolor[WG + px] = (acc.y < 1.0f) ? acc.y : 1.0f;
-                scolor[2 * WG + px] = (acc.z < 1.0f) ? acc.z : 1.0f;
+                if (v) {
+                    const uint32_t px = hinfo & 255u;
+                    scolor[px] = (acc.x < 1.0f) ? acc.x : 1.0f; // glm::min(vec3(1.0f), acc)
+                    scolor[WG + px] = (acc.y < 1.0f) ? acc.y : 1.0f;
+                    scolor[2 * WG + px] = (acc.z < 1.0f) ? acc.z : 1.0f;
+                }
             }
             RT_STAMP(8);
             lds_barrier();
@@ -1613,7 +1645,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 const F3 oc{scolor[tid], scolor[WG + tid], scolor[2 * WG + tid]};
                 if (first) res = oc;
                 else blend(res, cur_ratio, oc);
-                const float refl = HAS_MIRROR ? S.mat[hidx[my_slot] >> 8].refl : 0.0f; // `best` is not kept across B / C
+                const float refl = HAS_MIRROR ? S.mat[(hidx[my_slot] >> 8) & 0x7FFFFFu].refl : 0.0f; // `best` is not kept across B / C
                 if (!HAS_MIRROR || !((double) refl > EPS)) {
                     live = false;
                 } else {

@@ -26,6 +26,7 @@ extern "C" hipError_t rt_launch_wavefront_strict(const FrameArgs *, const DevObj
 extern "C" hipError_t rt_launch_wavefront_fast(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, const double *, const double *, hipStream_t);
 
 extern "C" size_t rt_wavefront_lds_bytes_strict(uint32_t, uint32_t, int, uint32_t, int);
+
 extern "C" hipError_t rt_launch_assemble_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" hipError_t rt_launch_pack_sparse_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t rt_launch_assemble_sparse_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, void *, uint32_t, uint32_t, hipStream_t);
@@ -100,6 +101,7 @@ struct rt_ctx {
     unsigned long long *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_done = nullptr;      // recorded behind every render: a render on ANOTHER stream waits for it (frames of a context are ordered)
+
     hipStream_t last_stream = nullptr;
     bool rendered = false;
     bool captured = false;      // the last render was recorded into a stream capture: ev_done was not (an event recorded inside a capture orders nothing outside it)
@@ -536,6 +538,7 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
         if (sd->light_is_spherical[i]) fa.pt_mask[i >> 5] |= 1u << (i & 31u);
     if (std::getenv("MI355RT_NOLEAN")) ctx->lean_ok = false; // (experiments)
     if (ctx->lean_ok) ctx->ord_split = 0u; // its waves are independent: a second workgroup per tile would shorten nothing
+
     if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u, 0) > 160u * 1024u) {
         return fail(RT_ERR_SCENE, "rt_create: scene needs %zu bytes of LDS per workgroup (limit 160 KiB)",
                     rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u, 0));
@@ -933,6 +936,7 @@ extern "C" int rt_destroy(rt_ctx *ctx)
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     if (ctx->ev_done) (void) hipEventDestroy(ctx->ev_done);
+
     delete ctx;
     return RT_OK;
 }

@@ -85,16 +85,25 @@ __device__ __forceinline__ uint32_t tile_py(uint32_t tid) { return (tid >> 7) * 
 // Diagnostic build only (make STAMPS=1): per-phase wave-cycle totals into counters[8..], read with
 // rt_debug_counters().  The product build contains no stamp.
 #ifdef RT_WF_STAMPS
-#define RT_STAMP_DECL unsigned long long ph_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long tl_ = clock64(); const unsigned long long w0_ = wall_clock64(); unsigned long long info_ = 0;
-#define RT_STAMP(i) do { unsigned long long t_ = clock64(); ph_[i] += t_ - tl_; tl_ = t_; } while (0)
+struct StampState {
+    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tl, w0, info = 0;
+    __device__ __forceinline__ StampState() : tl(clock64()), w0(wall_clock64()) {}
+};
+#define RT_STAMP_DECL StampState st_;
+#define RT_STAMP_ARG , StampState &st_
+#define RT_STAMP_PASS , st_
+#define RT_STAMP(i) do { unsigned long long t_ = clock64(); st_.ph[i] += t_ - st_.tl; st_.tl = t_; } while (0)
 // one private 16-word row per wave (pointer in counters[31]) -- no atomics, which would distort the timings.  Words 0-11: cycles
 // per phase; 12 / 13: constant-rate clock (100 MHz) at the wave's start / end, for tools/timeline.py
 #define RT_STAMP_FLUSH(c, lane) do { if ((lane) == 0) { unsigned long long *row_ = reinterpret_cast<unsigned long long *>((c)[31]) + \
-    ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; for (int i_ = 0; i_ < 12; i_++) row_[i_] = ph_[i_]; row_[12] = w0_; row_[13] = wall_clock64(); row_[14] = info_; \
+    ((size_t) (stamp_row_base_ + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16; for (int i_ = 0; i_ < 12; i_++) row_[i_] = st_.ph[i_]; row_[12] = st_.w0; row_[13] = wall_clock64(); row_[14] = st_.info; \
     row_[15] = ((unsigned long long) __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned) __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } } while (0)
-#define RT_STAMP_INFO(x) do { info_ = (x); } while (0)
+#define RT_STAMP_INFO(x) do { st_.info = (x); } while (0)
 #else
 #define RT_STAMP_DECL
+#define RT_STAMP_ARG
+#define RT_STAMP_PASS
 #define RT_STAMP(i)
 #define RT_STAMP_FLUSH(c, lane)
 #define RT_STAMP_INFO(x)
@@ -113,6 +122,7 @@ __device__ __forceinline__ uint32_t tile_py(uint32_t tid) { return (tid >> 7) * 
 #ifndef RT_WF_LEAN_OCC
 #define RT_WF_LEAN_OCC 6
 #endif
+
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR, bool LEAN = false>
 constexpr int wf_occupancy()
 {
@@ -806,6 +816,195 @@ __device__ __forceinline__ const ColdArgs &cold_args()
     return *(const ColdArgs *) (p + sizeof(HotArgs));
 }
 
+// ---- the lean path: one wave renders one 8 x 8 block, start to finish (LEAN instantiations only) ----
+// Scenes of unit spheres without mirrors (BASELINE configs 2 and 5).  A wave keeps the hits of its own 64 pixels IN REGISTERS -- no
+// compaction into a queue of the tile, hence no barrier after the staging one, no shadow bits, no colour exchange -- and walks the
+// lights IN ORDER, adding each unshadowed light's term to the pixel's colour as soon as its shadow test is done
+// (src/update-cpu.cpp:62-77 is that very loop).  What the queue bought (full lanes in the shadow phase of tiles on a silhouette) is
+// small where spheres cover many blocks: 1080p has 3.5 % more (block, light) items this way.  What it cost: five barriers per tile,
+// 12 KB of LDS, the one-lane-per-hit shading phase and its second pass over the normals and lights, the bits in between.
+// In: the lane's primary direction and whether its pixel is inside the image; `tile_` only labels the stamps.  Out: the pixel's colour,
+// the block's hit mask, the shader-clock ticks spent on its lights (`listing_`: the launch order wants them).
+struct LeanLds { // the LDS regions of the lean path: `hp` one slot per thread ([3][hp_stride]), the others one per wave
+    double *hp;
+    uint32_t hp_stride;
+    Ball *sball;
+    BoxH *sbox;
+    CullRec *screc;
+    const unsigned char *smem;
+    uint32_t crec_off, n_crec;
+};
+template <bool COUNT>
+__device__ __forceinline__ void lean_block(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj, const LeanLds &M, const DevLight *glight, Cnt<COUNT> &cnt,
+                                           uint32_t tile_, const D3 &o, const D3 &dir, bool live, bool listing_, const uint32_t lane, const uint32_t tid, const uint32_t wave,
+                                           F3 &res, unsigned long long &hm, unsigned long long &b_ticks RT_STAMP_ARG)
+{
+    (void) tile_;
+    double *hp = M.hp;
+    Ball *sball = M.sball;
+    BoxH *sbox = M.sbox;
+    CullRec *screc = M.screc;
+    const unsigned char *smem = M.smem;
+    struct { uint32_t crec, n_crec; } L{M.crec_off, M.n_crec};
+    ConstLights clight = (ConstLights) (glight + fa.n_lights);
+            if (live) cnt.add(0);
+            cnt.primary_traced();
+            RT_STAMP(1);
+            double best_t;
+            int best;
+            {
+                Mono m;
+                mono_set_o<false>(m, o);
+                mono_set_d<false>(m, dir);
+                mono_set_od<false>(m);
+                nearest<COUNT, false, false, true>(fa, S, gobj, m, live, lane, best_t, best, cnt);
+            }
+            RT_STAMP(2);
+            if (live) cnt.add(3, fa.n_obj);
+            const bool hit = live && best >= 0;
+            hm = __ballot(hit);
+            RT_STAMP_INFO(((unsigned long long) tile_ << 32) | (unsigned) __popcll(hm));
+            b_ticks = 0ull;
+            if (hm != 0ull) { // wave-uniform: this block has hits
+                const uint32_t bi = hit ? (uint32_t) best : 0u; // (every object is a unit sphere: table index == object index)
+                const UsEntry eo = S.us[bi];
+                const D3 sp{o.x + best_t * dir.x, o.y + best_t * dir.y, o.z + best_t * dir.z};
+                const D3 sn = sphere_normal(eo, sp);
+                if (hit) cnt.add(4);
+                hp[tid] = sp.x; hp[M.hp_stride + tid] = sp.y; hp[2 * M.hp_stride + tid] = sp.z; // this lane's own slot: only point lights need the hit point again
+                Mono sm;
+                mono_set_o<false>(sm, D3{sp.x + SHADOW_BIAS * sn.x, sp.y + SHADOW_BIAS * sn.y, sp.z + SHADOW_BIAS * sn.z});
+                // own_sphere_skippable.  The shadow ray of a hit on sphere s starts at o = p + 1e-2 n, outside s, and the reference tests it
+                // against s like against any other object (src/update-cpu.cpp:66-71).  Its t0 = F_s(o) does not depend on the light, so it
+                // is formed here once, with the reference's operations (us_t0).  For a directional light in front of the surface
+                // ((float) dot(n, l) > 0: the lanes the product traces at all) with |d|^2 > EPS that test cannot find a root > EPS while
+                // own_lo < t0 < own_hi:
+                //   * its computed t1 is 2 rho (n.d) up to rounding, rho = |o - centre|, and n.d >= -1.1e-7 |d| (dot(n, l) > 0 up to 3 ulp;
+                //     d is l rounded to FP32), so either t1 > 0 -- then, t0 being > 0, both roots are <= 0 (us_needs_solve) --
+                //   * or t1^2 <= 2 (2.2e-7 rho |d|)^2 + 2 (2.7e-15 S |d|)^2  with rho^2 = t0 + r^2 < 3 (r^2 + 1)  (t0 < own_hi = (r + 1)^2)  and
+                //     S = |o|_1 + |centre|_1 <= 2 |centre|_1 + 3 r + 3, which is below 4 |d|^2 t0 as soon as t0 > 1e-13 (r^2 + 1) + 1e-29 S^2:
+                //     the discriminant is negative and the solver returns -1 (include/surface_impl.h:141-144).
+                // own_lo = 1e-10 (r^2 + 1) + 1e-20 S^2 keeps three orders of magnitude between the two (rt_create); a true t0 is
+                // 0.02 r + 1e-4.  Lanes outside the window simply take the test.
+                const double t0_own = us_t0(eo, sm);
+                const bool skip_geom = hit && t0_own > (double) eo.own_lo && t0_own < (double) eo.own_hi;
+                const uint32_t b0 = (uint32_t) __builtin_amdgcn_readlane((int) bi, __builtin_ctzll(hm));
+                // every hit of the block on one sphere, all inside the window: the sphere's bit, cleared from the culling verdict at once
+                const unsigned long long own_all = (__ballot(hit && (bi != b0 || !skip_geom)) == 0ull && b0 < 64u) ? (1ull << b0) : 0ull;
+
+                // ---- the block's bounding box / ball and its culling records (phase A' of the other path), private to this wave ----
+                {
+                    const float inf = __builtin_inff();
+                    const float lox = wave_min_f(hit ? __double2float_rd(sp.x) : inf), hix = wave_max_f(hit ? __double2float_ru(sp.x) : -inf);
+                    const float loy = wave_min_f(hit ? __double2float_rd(sp.y) : inf), hiy = wave_max_f(hit ? __double2float_ru(sp.y) : -inf);
+                    const float loz = wave_min_f(hit ? __double2float_rd(sp.z) : inf), hiz = wave_max_f(hit ? __double2float_ru(sp.z) : -inf);
+                    const double dx = (double) hix - (double) lox, dy = (double) hiy - (double) loy, dz = (double) hiz - (double) loz;
+                    Ball b;
+                    b.cx = 0.5 * ((double) lox + (double) hix);
+                    b.cy = 0.5 * ((double) loy + (double) hiy);
+                    b.cz = 0.5 * ((double) loz + (double) hiz);
+                    b.R = 0.5 * sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-9) + 1.01e-2; // half diagonal (rounded up) + the shadow bias of the ray origins
+                    if (lane == 0) {
+                        sball[wave] = b;
+                        sbox[wave] = BoxH{0.5 * dx * (1.0 + 1e-9) + 1.01e-2, 0.5 * dy * (1.0 + 1e-9) + 1.01e-2, 0.5 * dz * (1.0 + 1e-9) + 1.01e-2, 0.0};
+                    }
+                    if (lane < L.n_crec) screc[wave * L.n_crec + lane] = cull_record(S.us[lane], b);
+                    if (lane == 0) cnt.cull(C_RECORDS, L.n_crec);
+                    // (written and read by this wave only; LDS executes a wave's accesses in order)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+                }
+                RT_STAMP(5);
+
+                // ---- lights in order: shadow test, then the light's term (src/update-cpu.cpp:62-77) ----
+                const unsigned long long b_t0 = listing_ ? __builtin_amdgcn_s_memtime() : 0ull;
+                const CullRec *my_crec = reinterpret_cast<const CullRec *>(smem + (L.crec + wave * L.n_crec * (uint32_t) sizeof(CullRec)));
+                // The lights through the constant address space (LightK, rt_scene_dev.h): one batch of scalar loads per light, its fields in
+                // SGPRs -- no vector register holds a per-light constant; the LDS copy of the lights is not used by this path.  One body
+                // per light kind, with nothing merged between them (a value that is uniform in one and per lane in the other would become a
+                // vector register in both).
+                const Ball *my_ball = sball + wave;
+                const BoxH *my_box = sbox + wave;
+                // Point lights first, shadow tests only: one bit per (lane, point light) in a register.  Their culling test is the widest
+                // stretch of this kernel in registers; in a pass of its own it does not meet the colour accumulators and constants of
+                // the ordered pass below, which only reads the bit when the light's turn comes (include/light_impl.h:19-21: (light -
+                // point) through FP32, max_t = 1).
+                const unsigned long long pt_mask = ((unsigned long long) fa.pt_mask[1] << 32) | fa.pt_mask[0];
+                unsigned long long pt_blocked = 0ull; // bit l: point light l is blocked for this lane's hit
+                for (unsigned long long pm = pt_mask; pm != 0ull; pm &= pm - 1ull) { // wave-uniform
+                    const uint32_t l = (uint32_t) __builtin_ctzll(pm);
+                    RT_LOAD_LIGHTK(lk, l)
+                    const D3 spl{hp[tid], hp[M.hp_stride + tid], hp[2 * M.hp_stride + tid]};
+                    const double dx = lk.p[0] - spl.x, dy = lk.p[1] - spl.y, dz = lk.p[2] - spl.z;
+                    const double q = dot3(sn, D3{dx, dy, dz});
+                    const double mag = fabs(sn.x * dx) + fabs(sn.y * dy) + fabs(sn.z * dz);
+                    const bool wanted = hit && !(q < -1e-9 * mag); // behind the surface by a margin 10^7 times the rounding: the term is +0 (as in the other path)
+                    if (COUNT || __any(wanted)) {
+                        Mono sd;
+                        sd.o = sm.o; sd.u0 = sm.u0;
+                        mono_set_d<false>(sd, D3{(double) (float) dx, (double) (float) dy, (double) (float) dz});
+                        mono_set_od<false>(sd);
+                        if (wanted) cnt.traced();
+                        const int blocker = shadow_blocker<COUNT, false, false, true, true>(fa, S, gobj, sd, 1.0, COUNT ? hit : wanted, wanted, my_ball, my_box, my_crec, lk, lane, cnt);
+                        if (hit) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
+                        if (hit && blocker != NO_BLOCKER) pt_blocked |= 1ull << l;
+                    } else if (COUNT && hit) {
+                        cnt.add(3, fa.n_obj);
+                    }
+                }
+                // ---- lights in order (src/update-cpu.cpp:62-77) ----
+                const MatEntry mt = S.mat[bi];
+                const F3 aop{mt.albedo[0] / PI_F, mt.albedo[1] / PI_F, mt.albedo[2] / PI_F}; // object_color / pi, once per hit
+                F3 acc{0.0f, 0.0f, 0.0f};
+                for (uint32_t l = 0; l < fa.n_lights; l++) {
+                    RT_LOAD_LIGHTK(lk, l)
+                    if (hit) cnt.add(1);
+                    if (!((pt_mask >> l) & 1ull)) { // ---- directional: include/light_impl.h:23-25, one direction for every ray ----
+                        const bool bfe = (lk.flags & 2u) != 0u;
+                        const float lam = (float) dot3(sn, D3{lk.p[0], lk.p[1], lk.p[2]}); // surface_color's (float) dot(n, dir), include/light_impl.h:42
+                        // a light behind the surface adds exactly +0 (all colours finite: bfe), shadowed or not: such lanes sit the light out
+                        const bool wanted = hit && (!bfe || 0.0f < lam);
+                        if (COUNT || __any(wanted)) {
+                            const bool quad_l = (lk.flags & 4u) != 0u; // (|d|^2 <= EPS: the reference takes its linear branch, to which the own-sphere argument does not apply)
+                            Mono sd;
+                            sd.o = sm.o; sd.u0 = sm.u0;
+                            sd.d = D3{lk.sdir[0], lk.sdir[1], lk.sdir[2]};
+                            sd.u2 = lk.u2;
+                            mono_set_od<false>(sd);
+                            if (wanted) cnt.traced();
+                            const int blocker = shadow_blocker<COUNT, false, false, false, true>(fa, S, gobj, sd, 1e6, COUNT ? hit : wanted, wanted, my_ball, my_box, my_crec, lk, lane, cnt, bi,
+                                                                                                 bfe && quad_l && wanted && skip_geom, (!COUNT && bfe && quad_l) ? own_all : 0ull);
+                            if (hit) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
+                            if (wanted && blocker == NO_BLOCKER) { // ((albedo / pi) * colour) * max(0, n.l), left to right (include/light_impl.h:43)
+                                const float mx = (0.0f < lam) ? lam : 0.0f;
+                                cnt.shaded();
+                                acc.x += aop.x * lk.color[0] * mx;
+                                acc.y += aop.y * lk.color[1] * mx;
+                                acc.z += aop.z * lk.color[2] * mx;
+                            }
+                        }
+                    } else if (hit && !((pt_blocked >> l) & 1ull)) { // ---- point light, not blocked (lanes that sat its test out add their +0 like the other path does) ----
+                        const D3 spl{hp[tid], hp[M.hp_stride + tid], hp[2 * M.hp_stride + tid]};
+                        const double lp[3] = {lk.p[0], lk.p[1], lk.p[2]};
+                        const float lc[3] = {lk.color[0], lk.color[1], lk.color[2]};
+                        const F3 col = surface_color_pre(lp, lc, true, spl, sn, aop);
+                        cnt.shaded();
+                        acc.x += col.x;
+                        acc.y += col.y;
+                        acc.z += col.z;
+                    }
+                }
+                if (hit) { // glm::min(vec3(1.0f), acc), src/update-cpu.cpp:77
+                    res.x = (acc.x < 1.0f) ? acc.x : 1.0f;
+                    res.y = (acc.y < 1.0f) ? acc.y : 1.0f;
+                    res.z = (acc.z < 1.0f) ? acc.z : 1.0f;
+                }
+                if (listing_) b_ticks = __builtin_amdgcn_s_memtime() - b_t0;
+                RT_STAMP(6);
+            }
+    }
+
 // HAS_MIRROR = some object has reflection_ratio > EPS.  Without mirrors every pixel is finished after round 0, the
 // round loop is known to run once and the bounce state (ray direction, blend ratio, depth) is dead during the shadow
 // phase -- which is what lets the mirror-free instantiation fit 128 VGPRs (4 waves per SIMD).
@@ -920,6 +1119,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     uint32_t *s_done = s_wcount + 15;                                 // [1] lean path: waves of this workgroup that have finished their block
 
     RT_STAMP_DECL
+    const uint32_t stamp_row_base_ = 0u;
+    (void) stamp_row_base_;
     // No prologue: 83 % of the tiles of a typical frame contain no hit at all, and for those the whole job is
     // "primary rays miss, store the background".  Round 0 therefore reads the (culled, tiny) part of the tables it
     // needs straight from global memory -- the blob is a few KB and lives in L2 / the scalar cache -- and the scene is
@@ -980,7 +1181,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         if (slot == 0 && tid == 0) {
             const uint32_t *ord_rd = fa.order_state + (size_t) fa.ord_read * fa.ord_stride;
             uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride;
-            for (uint32_t k = 0; k < 20; k += 4) *reinterpret_cast<uint4 *>(z + k) = make_uint4(0, 0, 0, 0);
+            for (uint32_t k = 0; k < RT_ORD_HDR; k += 4) *reinterpret_cast<uint4 *>(z + k) = make_uint4(0, 0, 0, 0);
             if (fa.ord_host) { fa.ord_host[0] = 0; fa.ord_host[1] = ord_rd[16]; }
         }
     }
@@ -1002,17 +1203,17 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             ConstWords ord_rd = (ConstWords) hot_ord_rd;
             const OrdHeader oh = ord_header(ord_rd, ((hot_flags >> 4) & 15u) | ((hot_flags >> 20) << 4)); // listed tiles per cost class, census, largest cost, half tiles
             // the per-tile word of an index-order slot is requested with them (for a list slot: tile 0's, unused)
-            const uint32_t idx_tile = slot >= hot_ord_cap ? slot - hot_ord_cap : 0u;
+            const uint32_t idx_tile = slot >= ord_slots ? slot - ord_slots : 0u;
             const uint32_t w = ord_rd[RT_ORD_HDR + idx_tile]; // (position in its class list << 5) | (class + 1), 0 = had no hits
             const uint32_t n_eff = ord_positions(oh) < hot_ord_cap ? ord_positions(oh) : hot_ord_cap; // positions in use (half tiles count twice)
             if (slot == 0 && lane == 0) {
                 uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride; // the generation the NEXT frame appends to
-                for (uint32_t k = 0; k < 20; k += 4) *reinterpret_cast<uint4 *>(z + k) = make_uint4(0, 0, 0, 0);
+                for (uint32_t k = 0; k < RT_ORD_HDR; k += 4) *reinterpret_cast<uint4 *>(z + k) = make_uint4(0, 0, 0, 0);
                 if (fa.ord_host) { fa.ord_host[0] = oh.n_listed + oh.n_candidates; fa.ord_host[1] = oh.census; } // host-mapped: sizes / switches later launches
             }
             uint32_t d_half = 0;
             uint32_t d_tile = slot, d_flags = oh.census * 64u < hot_n_tiles ? 4u : 0u; // 1 listed, 2 covered, 4 listing (the host's switch lags a few frames: same rule here), 8 leave
-            if (slot < hot_ord_cap) {
+            if (slot < ord_slots) {
                 if (slot >= n_eff) {
                     d_flags |= 8u;
                 } else {
@@ -1177,170 +1378,11 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         bool live = inside; // this pixel still has a ray to trace
         uint32_t ord_cls = 0, ord_pos = 0; // one thread per tile with hits: the tile's entry in the next frame's launch order
         if constexpr (LEAN) {
-            // ---------------- the lean path: one wave per 8 x 8 block, start to finish ----------------
-            // Scenes of unit spheres without mirrors (BASELINE configs 2 and 5).  A wave keeps the hits of its own 64 pixels IN
-            // REGISTERS -- no compaction into a queue of the tile, hence no barrier after the staging one, no shadow bits, no colour
-            // exchange -- and walks the lights IN ORDER, adding each unshadowed light's term to the pixel's colour as soon as its
-            // shadow test is done (src/update-cpu.cpp:62-77 is that very loop).  What the queue bought (full lanes in the shadow phase
-            // of tiles on a silhouette) is small where spheres cover many blocks: 1080p has 3.5 % more (block, light) items this way.
-            // What it cost: five barriers per tile, 12 KB of LDS, the one-lane-per-hit shading phase and its second pass over the
-            // normals and lights (10 % of the wave-cycles), the bits in between.
-            if (inside) cnt.add(0);
-            cnt.primary_traced();
-            RT_STAMP(1);
-            double best_t;
-            int best;
-            {
-                Mono m;
-                mono_set_o<false>(m, o);
-                mono_set_d<false>(m, dir);
-                mono_set_od<false>(m);
-                nearest<COUNT, false, false, true>(fa, S, gobj, m, live, lane, best_t, best, cnt);
-            }
-            RT_STAMP(2);
-            if (live) cnt.add(3, fa.n_obj);
-            const bool hit = live && best >= 0;
-            const unsigned long long hm = __ballot(hit);
-            RT_STAMP_INFO(((unsigned long long) tile << 32) | (unsigned) __popcll(hm));
-            unsigned long long b_ticks = 0ull;
-            if (hm != 0ull) { // wave-uniform: this block has hits
-                const uint32_t bi = hit ? (uint32_t) best : 0u; // (every object is a unit sphere: table index == object index)
-                const UsEntry eo = S.us[bi];
-                const D3 sp{o.x + best_t * dir.x, o.y + best_t * dir.y, o.z + best_t * dir.z};
-                const D3 sn = sphere_normal(eo, sp);
-                if (hit) cnt.add(4);
-                hp[tid] = sp.x; hp[WG + tid] = sp.y; hp[2 * WG + tid] = sp.z; // this lane's own slot: only point lights need the hit point again
-                Mono sm;
-                mono_set_o<false>(sm, D3{sp.x + SHADOW_BIAS * sn.x, sp.y + SHADOW_BIAS * sn.y, sp.z + SHADOW_BIAS * sn.z});
-                // own_sphere_skippable.  The shadow ray of a hit on sphere s starts at o = p + 1e-2 n, outside s, and the reference tests it
-                // against s like against any other object (src/update-cpu.cpp:66-71).  Its t0 = F_s(o) does not depend on the light, so it
-                // is formed here once, with the reference's operations (us_t0).  For a directional light in front of the surface
-                // ((float) dot(n, l) > 0: the lanes the product traces at all) with |d|^2 > EPS that test cannot find a root > EPS while
-                // own_lo < t0 < own_hi:
-                //   * its computed t1 is 2 rho (n.d) up to rounding, rho = |o - centre|, and n.d >= -1.1e-7 |d| (dot(n, l) > 0 up to 3 ulp;
-                //     d is l rounded to FP32), so either t1 > 0 -- then, t0 being > 0, both roots are <= 0 (us_needs_solve) --
-                //   * or t1^2 <= 2 (2.2e-7 rho |d|)^2 + 2 (2.7e-15 S |d|)^2  with rho^2 = t0 + r^2 < 3 (r^2 + 1)  (t0 < own_hi = (r + 1)^2)  and
-                //     S = |o|_1 + |centre|_1 <= 2 |centre|_1 + 3 r + 3, which is below 4 |d|^2 t0 as soon as t0 > 1e-13 (r^2 + 1) + 1e-29 S^2:
-                //     the discriminant is negative and the solver returns -1 (include/surface_impl.h:141-144).
-                // own_lo = 1e-10 (r^2 + 1) + 1e-20 S^2 keeps three orders of magnitude between the two (rt_create); a true t0 is
-                // 0.02 r + 1e-4.  Lanes outside the window simply take the test.
-                const double t0_own = us_t0(eo, sm);
-                const bool skip_geom = hit && t0_own > (double) eo.own_lo && t0_own < (double) eo.own_hi;
-                const uint32_t b0 = (uint32_t) __builtin_amdgcn_readlane((int) bi, __builtin_ctzll(hm));
-                // every hit of the block on one sphere, all inside the window: the sphere's bit, cleared from the culling verdict at once
-                const unsigned long long own_all = (__ballot(hit && (bi != b0 || !skip_geom)) == 0ull && b0 < 64u) ? (1ull << b0) : 0ull;
-
-                // ---- the block's bounding box / ball and its culling records (phase A' of the other path), private to this wave ----
-                {
-                    const float inf = __builtin_inff();
-                    const float lox = wave_min_f(hit ? __double2float_rd(sp.x) : inf), hix = wave_max_f(hit ? __double2float_ru(sp.x) : -inf);
-                    const float loy = wave_min_f(hit ? __double2float_rd(sp.y) : inf), hiy = wave_max_f(hit ? __double2float_ru(sp.y) : -inf);
-                    const float loz = wave_min_f(hit ? __double2float_rd(sp.z) : inf), hiz = wave_max_f(hit ? __double2float_ru(sp.z) : -inf);
-                    const double dx = (double) hix - (double) lox, dy = (double) hiy - (double) loy, dz = (double) hiz - (double) loz;
-                    Ball b;
-                    b.cx = 0.5 * ((double) lox + (double) hix);
-                    b.cy = 0.5 * ((double) loy + (double) hiy);
-                    b.cz = 0.5 * ((double) loz + (double) hiz);
-                    b.R = 0.5 * sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-9) + 1.01e-2; // half diagonal (rounded up) + the shadow bias of the ray origins
-                    if (lane == 0) {
-                        sball[wave] = b;
-                        sbox[wave] = BoxH{0.5 * dx * (1.0 + 1e-9) + 1.01e-2, 0.5 * dy * (1.0 + 1e-9) + 1.01e-2, 0.5 * dz * (1.0 + 1e-9) + 1.01e-2, 0.0};
-                    }
-                    if (lane < L.n_crec) screc[wave * L.n_crec + lane] = cull_record(S.us[lane], b);
-                    if (lane == 0) cnt.cull(C_RECORDS, L.n_crec);
-                    // (written and read by this wave only; LDS executes a wave's accesses in order)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-                }
-                RT_STAMP(5);
-
-                // ---- lights in order: shadow test, then the light's term (src/update-cpu.cpp:62-77) ----
-                const unsigned long long b_t0 = listing ? __builtin_amdgcn_s_memtime() : 0ull;
-                const CullRec *my_crec = reinterpret_cast<const CullRec *>(smem + (L.crec + wave * L.n_crec * (uint32_t) sizeof(CullRec)));
-                // The lights through the constant address space (LightK, rt_scene_dev.h): one batch of scalar loads per light, its fields in
-                // SGPRs -- no vector register holds a per-light constant; the LDS copy of the lights is not used by this path.  One body
-                // per light kind, with nothing merged between them (a value that is uniform in one and per lane in the other would become a
-                // vector register in both).
-                const Ball *my_ball = sball + wave;
-                const BoxH *my_box = sbox + wave;
-                // Point lights first, shadow tests only: one bit per (lane, point light) in a register.  Their culling test is the widest
-                // stretch of this kernel in registers; in a pass of its own it does not meet the colour accumulators and constants of
-                // the ordered pass below, which only reads the bit when the light's turn comes (include/light_impl.h:19-21: (light -
-                // point) through FP32, max_t = 1).
-                const unsigned long long pt_mask = ((unsigned long long) fa.pt_mask[1] << 32) | fa.pt_mask[0];
-                unsigned long long pt_blocked = 0ull; // bit l: point light l is blocked for this lane's hit
-                for (unsigned long long pm = pt_mask; pm != 0ull; pm &= pm - 1ull) { // wave-uniform
-                    const uint32_t l = (uint32_t) __builtin_ctzll(pm);
-                    RT_LOAD_LIGHTK(lk, l)
-                    const D3 spl{hp[tid], hp[WG + tid], hp[2 * WG + tid]};
-                    const double dx = lk.p[0] - spl.x, dy = lk.p[1] - spl.y, dz = lk.p[2] - spl.z;
-                    const double q = dot3(sn, D3{dx, dy, dz});
-                    const double mag = fabs(sn.x * dx) + fabs(sn.y * dy) + fabs(sn.z * dz);
-                    const bool wanted = hit && !(q < -1e-9 * mag); // behind the surface by a margin 10^7 times the rounding: the term is +0 (as in the other path)
-                    if (COUNT || __any(wanted)) {
-                        Mono sd;
-                        sd.o = sm.o; sd.u0 = sm.u0;
-                        mono_set_d<false>(sd, D3{(double) (float) dx, (double) (float) dy, (double) (float) dz});
-                        mono_set_od<false>(sd);
-                        if (wanted) cnt.traced();
-                        const int blocker = shadow_blocker<COUNT, false, false, true, true>(fa, S, gobj, sd, 1.0, COUNT ? hit : wanted, wanted, my_ball, my_box, my_crec, lk, lane, cnt);
-                        if (hit) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
-                        if (hit && blocker != NO_BLOCKER) pt_blocked |= 1ull << l;
-                    } else if (COUNT && hit) {
-                        cnt.add(3, fa.n_obj);
-                    }
-                }
-                // ---- lights in order (src/update-cpu.cpp:62-77) ----
-                const MatEntry mt = S.mat[bi];
-                const F3 aop{mt.albedo[0] / PI_F, mt.albedo[1] / PI_F, mt.albedo[2] / PI_F}; // object_color / pi, once per hit
-                F3 acc{0.0f, 0.0f, 0.0f};
-                for (uint32_t l = 0; l < fa.n_lights; l++) {
-                    RT_LOAD_LIGHTK(lk, l)
-                    if (hit) cnt.add(1);
-                    if (!((pt_mask >> l) & 1ull)) { // ---- directional: include/light_impl.h:23-25, one direction for every ray ----
-                        const bool bfe = (lk.flags & 2u) != 0u;
-                        const float lam = (float) dot3(sn, D3{lk.p[0], lk.p[1], lk.p[2]}); // surface_color's (float) dot(n, dir), include/light_impl.h:42
-                        // a light behind the surface adds exactly +0 (all colours finite: bfe), shadowed or not: such lanes sit the light out
-                        const bool wanted = hit && (!bfe || 0.0f < lam);
-                        if (COUNT || __any(wanted)) {
-                            const bool quad_l = (lk.flags & 4u) != 0u; // (|d|^2 <= EPS: the reference takes its linear branch, to which the own-sphere argument does not apply)
-                            Mono sd;
-                            sd.o = sm.o; sd.u0 = sm.u0;
-                            sd.d = D3{lk.sdir[0], lk.sdir[1], lk.sdir[2]};
-                            sd.u2 = lk.u2;
-                            mono_set_od<false>(sd);
-                            if (wanted) cnt.traced();
-                            const int blocker = shadow_blocker<COUNT, false, false, false, true>(fa, S, gobj, sd, 1e6, COUNT ? hit : wanted, wanted, my_ball, my_box, my_crec, lk, lane, cnt, bi,
-                                                                                                 bfe && quad_l && wanted && skip_geom, (!COUNT && bfe && quad_l) ? own_all : 0ull);
-                            if (hit) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
-                            if (wanted && blocker == NO_BLOCKER) { // ((albedo / pi) * colour) * max(0, n.l), left to right (include/light_impl.h:43)
-                                const float mx = (0.0f < lam) ? lam : 0.0f;
-                                cnt.shaded();
-                                acc.x += aop.x * lk.color[0] * mx;
-                                acc.y += aop.y * lk.color[1] * mx;
-                                acc.z += aop.z * lk.color[2] * mx;
-                            }
-                        }
-                    } else if (hit && !((pt_blocked >> l) & 1ull)) { // ---- point light, not blocked (lanes that sat its test out add their +0 like the other path does) ----
-                        const D3 spl{hp[tid], hp[WG + tid], hp[2 * WG + tid]};
-                        const double lp[3] = {lk.p[0], lk.p[1], lk.p[2]};
-                        const float lc[3] = {lk.color[0], lk.color[1], lk.color[2]};
-                        const F3 col = surface_color_pre(lp, lc, true, spl, sn, aop);
-                        cnt.shaded();
-                        acc.x += col.x;
-                        acc.y += col.y;
-                        acc.z += col.z;
-                    }
-                }
-                if (hit) { // glm::min(vec3(1.0f), acc), src/update-cpu.cpp:77
-                    res.x = (acc.x < 1.0f) ? acc.x : 1.0f;
-                    res.y = (acc.y < 1.0f) ? acc.y : 1.0f;
-                    res.z = (acc.z < 1.0f) ? acc.z : 1.0f;
-                }
-                if (listing) b_ticks = __builtin_amdgcn_s_memtime() - b_t0;
-                RT_STAMP(6);
-            }
+            // (lean_block, defined at the top of the kernel: this wave's own 8 x 8 quadrant of the tile)
+            unsigned long long hm = 0ull, b_ticks = 0ull;
+            LeanLds M;
+            M.hp = hp; M.hp_stride = WG; M.sball = sball; M.sbox = sbox; M.screc = screc; M.smem = smem; M.crec_off = L.crec; M.n_crec = L.n_crec;
+            lean_block<COUNT>(fa, S, gobj, M, glight, cnt, tile, o, dir, live, listing, lane, tid, wave, res, hm, b_ticks RT_STAMP_PASS);
             // ---- the next frame's launch order: the last wave of the workgroup to get here speaks for the tile ----
             // cost = shader-clock ticks / 64 its waves spent on their lights, summed (what the tile takes of its CU)
             if (ord_wr && lane == 0) { // launch-uniform x one lane per wave

@@ -115,6 +115,9 @@ struct rt_ctx {
     uint32_t *h_listed = nullptr; // host-mapped words the kernel writes (FrameArgs::ord_host)
     uint32_t ord_split = 0;       // FrameArgs::ord_split of non-sparse frames
     bool lean_ok = false;         // the scene qualifies for the wave-per-block instantiation (FrameArgs::lean; dense frames only)
+    bool lean_now = true;         // ... and it renders the current frames (it does not while few tiles have hits: see render_impl)
+    uint32_t wg_slots = 1536;     // workgroup slots of the device for these kernels (six per CU)
+    int lean_force = 0;           // MI355RT_LEAN=always / never (experiments)
     bool ord_on = true;           // launch-order feedback in use (off while most tiles have hits)
 };
 
@@ -537,7 +540,11 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
     for (uint32_t i = 0; i < sd->n_lights && i < 64u; i++)
         if (sd->light_is_spherical[i]) fa.pt_mask[i >> 5] |= 1u << (i & 31u);
     if (std::getenv("MI355RT_NOLEAN")) ctx->lean_ok = false; // (experiments)
-    if (ctx->lean_ok) ctx->ord_split = 0u; // its waves are independent: a second workgroup per tile would shorten nothing
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0) ctx->wg_slots = 6u * (uint32_t) cus;
+        if (const char *e = std::getenv("MI355RT_LEAN")) ctx->lean_force = (e[0] == 'a') ? 1 : ((e[0] == 'n') ? -1 : 0);
+    }
 
     if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u, 0) > 160u * 1024u) {
         return fail(RT_ERR_SCENE, "rt_create: scene needs %zu bytes of LDS per workgroup (limit 160 KiB)",
@@ -588,6 +595,7 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
             if (rc == RT_OK && hipHostMalloc((void **) &ctx->h_listed, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) {
                 ctx->h_listed[0] = 0;
                 ctx->h_listed[1] = 0;
+                ctx->h_listed[2] = 0xFFFFFFFFu; // (nothing known yet: the wave-per-block instantiation starts)
                 if (hipHostGetDevicePointer((void **) &fa.ord_host, ctx->h_listed, 0) != hipSuccess) {
                     (void) hipHostFree(ctx->h_listed);
                     ctx->h_listed = nullptr;
@@ -622,7 +630,18 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
     FrameArgs &fa = ctx->fa;
     fa.sparse = sparse ? 1u : 0u;
     fa.sparse_cap = sparse ? sparse_cap : 0u;
-    fa.lean = (ctx->lean_ok && !sparse) ? 1u : 0u;
+    // Which instantiation renders a scene of unit spheres?  The wave-per-block one ("lean") executes a quarter fewer instructions per
+    // frame and wins wherever the GPU is full (4K 120 -> 91 us, 8K 425 -> 306, the 1080p start pose 44 -> 38).  The general one splits
+    // costly tiles over two workgroups and every tile's lights over its four waves, which is what counts while few tiles have hits and
+    // the frame ends with its slowest wave (orbit poses 5 / 6 at 1080p: 40 us against 54).  The previous frames' count of tiles with
+    // hits decides, with a hysteresis: lean from 0.65 of the workgroup slots up, back below 0.55.
+    if (ctx->lean_ok && ctx->h_listed && ctx->lean_force == 0) {
+        const uint32_t tiles = ((volatile uint32_t *) ctx->h_listed)[2]; // tiles with hits a few frames ago (listed, or the census' estimate while the lists are off)
+        if (ctx->lean_now ? (uint64_t) tiles * 100u < (uint64_t) ctx->wg_slots * 55u : (uint64_t) tiles * 100u >= (uint64_t) ctx->wg_slots * 65u) ctx->lean_now = !ctx->lean_now;
+    } else {
+        ctx->lean_now = ctx->lean_force >= 0;
+    }
+    fa.lean = (ctx->lean_ok && ctx->lean_now && !sparse) ? 1u : 0u;
     std::memcpy(fa.cam, cam, sizeof(double) * 16);
     // g_ray_origin = camera_matrix * (0,0,0,1), src/update-cpu.cpp:123 -- glm order (m0*x + m1*y) + (m2*z + m3*w)
     for (int r = 0; r < 3; r++) fa.origin[r] = (cam[0 + r] * 0.0 + cam[4 + r] * 0.0) + (cam[8 + r] * 0.0 + cam[12 + r] * 1.0);
@@ -706,7 +725,8 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
         }
         fa.ord_cap = cap;
         fa.ord_on = ctx->ord_on ? 1u : 0u;
-        fa.ord_split = fa.sparse ? 0u : ctx->ord_split; // (a sparse message has one slot per tile)
+        fa.ord_split = (fa.sparse || fa.lean) ? 0u : ctx->ord_split; // (a sparse message has one slot per tile; the lean instantiation's waves are independent:
+                                                                     // a second workgroup per tile would shorten nothing)
         // this frame's number for the per-tile "entered by" words of split tiles: 1 .. 0xFFFFFFF0, never 0 (the words start out 0).  The
         // election is an atomicMax, so when the number starts over (every 2^32 - 16 frames) the words are cleared first -- the same
         // guard the tile-word tag has above.

@@ -816,6 +816,49 @@ __device__ __forceinline__ const ColdArgs &cold_args()
     return *(const ColdArgs *) (p + sizeof(HotArgs));
 }
 
+// The lean path's shadow test for ONE directional light with |d|^2 > EPS (product builds, scenes of at most 64 unit spheres, all of them
+// cullable): is the lane's shadow ray blocked?  The same decisions as shadow_blocker<.., SPHERICAL = false, OWN = true> -- same culling
+// records, same box stage, same own-sphere rule, same reference arithmetic per surviving sphere -- laid out for the common case, in
+// which no sphere survives the culling: nothing that only the survivors need (the ray's t1 part, the discriminant's factor) is formed
+// before it is known that there are any, the light's constants are scalar operands (LightK), and there is no loop over sphere groups.
+__device__ __forceinline__ bool lean_dir_blocked(const UsEntry *us, const CullRec *crec, const BoxH *boxp, const D3 &o, double u0, const LightK &lk, bool wanted,
+                                                 uint32_t own, bool own_skip, unsigned long long own_excl, uint32_t n_us, uint32_t lane)
+{
+    const D3 d{lk.sdir[0], lk.sdir[1], lk.sdir[2]};
+    unsigned long long it = __ballot(lane < n_us && crec_relevant(crec[lane], d, lk.inv_uu, lk.len_u));
+    if (__popcll(it) >= BOX_STAGE_MIN) it &= __ballot(lane < n_us && crec_in_box_shadow(crec[lane], *boxp, d, lk.s_yz, lk.s_xz, lk.s_xy));
+    it &= ~own_excl;
+    if (it == 0ull) return false; // wave-uniform: nothing can block any ray of this block
+    // the ray's part of t1 (mono_set_od: 2 o.d summed as the reference sums it)
+    const double u1 = (2.0 * o.x * d.x + 2.0 * o.y * d.y) + 2.0 * o.z * d.z;
+    unsigned long long cand = 0ull;
+    do { // wave-uniform loop over the spheres that survived the culling
+        const uint32_t b = (uint32_t) __builtin_ctzll(it);
+        it &= it - 1ull;
+        const bool act = wanted && !(own_skip && own == b); // lanes whose own sphere this is sit it out (own_sphere_skippable)
+        if (!__any(act)) continue;
+        const UsEntry e = us[b];
+        const double t1 = ((u1 + e.kx * d.x) + e.ky * d.y) + e.kz * d.z;           // us_t1
+        const double t0 = (((u0 + e.kx * o.x) + e.ky * o.y) + e.kz * o.z) + e.c;   // us_t0
+        const bool need = act && us_needs_solve(true, lk.four_u2, t1, t0);
+        cand |= need ? (1ull << b) : 0ull;
+    } while (it != 0ull);
+    bool blocked = false;
+    while (cand != 0ull) { // per lane: the few spheres whose root must actually be computed
+        const uint32_t b = (uint32_t) __builtin_ctzll(cand);
+        cand &= cand - 1ull;
+        const UsEntry e = us[b]; // LDS gather
+        const double t1 = ((u1 + e.kx * d.x) + e.ky * d.y) + e.kz * d.z;
+        const double t0 = (((u0 + e.kx * o.x) + e.ky * o.y) + e.kz * o.z) + e.c;
+        const double t = solve_quadlin(lk.u2, t1, t0);
+        if (t > EPS && t < 1e6) { // src/update-cpu.cpp:68, max_t of a directional light (include/light_impl.h:24)
+            blocked = true;
+            break;
+        }
+    }
+    return blocked;
+}
+
 // ---- the lean path: one wave renders one 8 x 8 block, start to finish (LEAN instantiations only) ----
 // Scenes of unit spheres without mirrors (BASELINE configs 2 and 5).  A wave keeps the hits of its own 64 pixels IN REGISTERS -- no
 // compaction into a queue of the tile, hence no barrier after the staging one, no shadow bits, no colour exchange -- and walks the
@@ -967,14 +1010,19 @@ __device__ __forceinline__ void lean_block(const FrameArgs &fa, const SceneLds &
                         const bool wanted = hit && (!bfe || 0.0f < lam);
                         if (COUNT || __any(wanted)) {
                             const bool quad_l = (lk.flags & 4u) != 0u; // (|d|^2 <= EPS: the reference takes its linear branch, to which the own-sphere argument does not apply)
-                            Mono sd;
-                            sd.o = sm.o; sd.u0 = sm.u0;
-                            sd.d = D3{lk.sdir[0], lk.sdir[1], lk.sdir[2]};
-                            sd.u2 = lk.u2;
-                            mono_set_od<false>(sd);
                             if (wanted) cnt.traced();
-                            const int blocker = shadow_blocker<COUNT, false, false, false, true>(fa, S, gobj, sd, 1e6, COUNT ? hit : wanted, wanted, my_ball, my_box, my_crec, lk, lane, cnt, bi,
-                                                                                                 bfe && quad_l && wanted && skip_geom, (!COUNT && bfe && quad_l) ? own_all : 0ull);
+                            int blocker;
+                            if (!COUNT && bfe && quad_l && fa.n_us <= 64u) { // wave-uniform: the common case, in its own lay-out (same decisions)
+                                blocker = lean_dir_blocked(S.us, my_crec, my_box, sm.o, sm.u0, lk, wanted, bi, skip_geom, own_all, fa.n_us, lane) ? 0 : NO_BLOCKER;
+                            } else {
+                                Mono sd;
+                                sd.o = sm.o; sd.u0 = sm.u0;
+                                sd.d = D3{lk.sdir[0], lk.sdir[1], lk.sdir[2]};
+                                sd.u2 = lk.u2;
+                                mono_set_od<false>(sd);
+                                blocker = shadow_blocker<COUNT, false, false, false, true>(fa, S, gobj, sd, 1e6, COUNT ? hit : wanted, wanted, my_ball, my_box, my_crec, lk, lane, cnt, bi,
+                                                                                           bfe && quad_l && wanted && skip_geom, (!COUNT && bfe && quad_l) ? own_all : 0ull);
+                            }
                             if (hit) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
                             if (wanted && blocker == NO_BLOCKER) { // ((albedo / pi) * colour) * max(0, n.l), left to right (include/light_impl.h:43)
                                 const float mx = (0.0f < lam) ? lam : 0.0f;
@@ -1182,7 +1230,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             const uint32_t *ord_rd = fa.order_state + (size_t) fa.ord_read * fa.ord_stride;
             uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride;
             for (uint32_t k = 0; k < RT_ORD_HDR; k += 4) *reinterpret_cast<uint4 *>(z + k) = make_uint4(0, 0, 0, 0);
-            if (fa.ord_host) { fa.ord_host[0] = 0; fa.ord_host[1] = ord_rd[16]; }
+            if (fa.ord_host) { fa.ord_host[0] = 0; fa.ord_host[1] = ord_rd[16]; fa.ord_host[2] = ord_rd[16] * 16u; } // [2]: tiles with hits (here: the census' estimate)
         }
     }
     if (hot_flags & 2u) { // launch-uniform
@@ -1209,7 +1257,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             if (slot == 0 && lane == 0) {
                 uint32_t *z = fa.order_state + (size_t) fa.ord_zero * fa.ord_stride; // the generation the NEXT frame appends to
                 for (uint32_t k = 0; k < RT_ORD_HDR; k += 4) *reinterpret_cast<uint4 *>(z + k) = make_uint4(0, 0, 0, 0);
-                if (fa.ord_host) { fa.ord_host[0] = oh.n_listed + oh.n_candidates; fa.ord_host[1] = oh.census; } // host-mapped: sizes / switches later launches
+                if (fa.ord_host) { fa.ord_host[0] = oh.n_listed + oh.n_candidates; fa.ord_host[1] = oh.census; fa.ord_host[2] = oh.n_listed; } // host-mapped: sizes / switches later launches
             }
             uint32_t d_half = 0;
             uint32_t d_tile = slot, d_flags = oh.census * 64u < hot_n_tiles ? 4u : 0u; // 1 listed, 2 covered, 4 listing (the host's switch lags a few frames: same rule here), 8 leave

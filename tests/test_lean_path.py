@@ -2,6 +2,8 @@
 dense output (rt_wavefront.hip, "the lean path").  It must produce the frames of the general instantiation (RT_FLAG_NOLEAN)
 and of the oracle bit for bit; its own-sphere rule (a shadow ray that leaves a sphere towards a light in front of the
 surface is not tested against that sphere) is exercised where its window could matter."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,13 @@ from conftest import scene_path
 from test_gpu_parity import oracle_from, render_desc, random_scene
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _lean_always(monkeypatch):
+    """rt_create reads MI355RT_LEAN: frames as small as these would otherwise switch to the general instantiation after the first one
+    (few tiles with hits: render_impl in rt_capi.cpp); the adaptive choice itself is covered by test_adaptive_choice_of_the_instantiation."""
+    monkeypatch.setenv("MI355RT_LEAN", "always")
 
 
 def _three_way(pkg, oracle, sc, cam=None):
@@ -129,3 +138,21 @@ def test_counters_after_a_camera_cut(pkg, oracle, flags):
         for k in ("primary_rays", "shadow_rays", "reflect_rays", "tests"):
             assert got[k] == want[k], (k, got, want)
     r.cleanup_update()
+
+
+def test_adaptive_choice_of_the_instantiation(pkg, monkeypatch):
+    """Without MI355RT_LEAN the host picks the instantiation per frame from the previous frames' count of tiles with hits (lean while the GPU
+    is full, the general one -- which splits costly tiles -- while few tiles have hits).  The frames must not notice the switches: a camera
+    that moves between a view full of spheres, a sparse one and an empty one, every frame equal to a fresh general-instantiation render."""
+    monkeypatch.delenv("MI355RT_LEAN", raising=False)
+    sc = pkg.Scene.load_from_file(scene_path("20spheres")).set_size(1920, 1080)
+    r = pkg.Renderer(sc, device=0)
+    ref = pkg.Renderer(sc, device=0, flags=pkg.RT_FLAG_NOLEAN | pkg.RT_FLAG_STATIC_ORDER)
+    poses = [(0, 0, 0, 90, 0)] * 6 + [(19, 2, 15, 180, 0)] * 8 + [(0, 0, 0, -90, 0)] * 4 + [(0, 0, 0, 90, 0)] * 8
+    for i, (x, y, z, yaw, pitch) in enumerate(poses):
+        cam = pkg.camera_matrix((x, y, z), yaw, pitch)
+        r.update(cam)
+        ref.update(cam)
+        assert np.array_equal(r.download(), ref.download()), f"frame {i}"
+    r.cleanup_update()
+    ref.cleanup_update()

@@ -11,6 +11,8 @@ import sys
 
 import numpy as np
 
+os.environ["MI355RT_LEAN"] = "always"   # (rt_create reads it: small frames would otherwise switch to the general instantiation after the first frame)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -162,7 +162,11 @@ def algorithmic_flops(cnt, table, arr):
     n_l = max(1, len(kinds))
     f_pt = float(sum(1 for k in kinds if k)) / n_l                      # share of point lights (shadow rays are hits x lights)
     f = 0.0
-    f += ex["unitsq"] * u["test_unitsq"] + ex["quadric"] * u["test_quadric"] + ex["linear"] * u["test_linear"] + ex["cubic"] * u["test_cubic_expand"]
+    # degree-3 surfaces: the strict build expands F(o + t d) term by term like the reference; the FMA build forms it from the surface's Taylor data at the ray origin
+    # (once per hit and wave, `cubic_points`) -- the device counts a point only where one is formed, so the choice of the per-test cost follows it
+    cub_unit = u["test_cubic_expand"] if cnt.get("cubic_points", 0) else u.get("test_cubic_dense", u["test_cubic_expand"])
+    f += ex["unitsq"] * u["test_unitsq"] + ex["quadric"] * u["test_quadric"] + ex["linear"] * u["test_linear"] + ex["cubic"] * cub_unit
+    f += cnt.get("cubic_points", 0) * u.get("cubic_point", 0)
     f += unit("solve_unitsq", so["unitsq"]) + unit("solve_quadric", so["quadric"]) + unit("solve_linear", so["linear"])
     f += unit("cubic_cardano", cb["cardano"]) + unit("cubic_trig", cb["trig"]) + unit("cubic_quadratic", cb["quad"]) + unit("cubic_linear", cb["linear"])
     n_us = max(1, ex_objects_unitsq(arr))

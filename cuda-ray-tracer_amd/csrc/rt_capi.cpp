@@ -15,6 +15,7 @@
 
 #include "mi355rt.h"
 #include "rt_scene_dev.h"
+#include "rt_math.hpp" // (rtm::cubic_at, host side: the Taylor data of degree-3 objects at the frame's ray origin)
 #include "scene-exception.h"
 #include "scene.h"
 #include "camera.h"
@@ -114,6 +115,7 @@ struct rt_ctx {
     uint32_t tag = 0;   // frame tag of the scan workgroups' tile words (FrameArgs::tile_state); unique per render, never 0
     uint32_t *h_listed = nullptr; // host-mapped words the kernel writes (FrameArgs::ord_host)
     uint32_t ord_split = 0;       // FrameArgs::ord_split of non-sparse frames
+    std::vector<double> cub_coefs; // the 20 coefficients of the first RT_CUB_AT_MAX degree-3 objects (FrameArgs::cub_at is formed from them every frame)
     bool lean_ok = false;         // the scene qualifies for the wave-per-block instantiation (FrameArgs::lean; dense frames only)
     bool lean_now = true;         // ... and it renders the current frames (it does not while few tiles have hits: see render_impl)
     uint32_t wg_slots = 1536;     // workgroup slots of the device for these kernels (six per CU)
@@ -430,6 +432,7 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
     for (uint32_t i = 0; i < sd->n_objects; i++) {
         const DevObject &o = objs[i];
         if (o.cls & RT_CLS_CUBIC) {
+            if (t_cub.size() < RT_CUB_AT_MAX) ctx->cub_coefs.insert(ctx->cub_coefs.end(), o.c, o.c + RT_NCOEF);
             t_cub.push_back(i);
         } else if (o.cls & RT_CLS_UNITSQ) {
             UsEntry e{};
@@ -646,6 +649,11 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
     // g_ray_origin = camera_matrix * (0,0,0,1), src/update-cpu.cpp:123 -- glm order (m0*x + m1*y) + (m2*z + m3*w)
     for (int r = 0; r < 3; r++) fa.origin[r] = (cam[0 + r] * 0.0 + cam[4 + r] * 0.0) + (cam[8 + r] * 0.0 + cam[12 + r] * 1.0);
 
+    for (size_t j = 0; j * RT_NCOEF < ctx->cub_coefs.size(); j++) { // degree-3 objects: F, grad F, half Hessian at the frame's ray origin (rt_math.hpp, cubic_at)
+        const rtm::CubicAt a = rtm::cubic_at(ctx->cub_coefs.data() + j * RT_NCOEF, rtm::D3{fa.origin[0], fa.origin[1], fa.origin[2]});
+        const double v[10] = {a.f, a.gx, a.gy, a.gz, a.hxx, a.hyy, a.hzz, a.hxy, a.hxz, a.hyz};
+        std::memcpy(fa.cub_at[j], v, sizeof(v));
+    }
     { // tile pyramids of the early-out test (FrameArgs::tile_nt): inverse transpose of the camera's 3x3 part
         const double a = cam[0], b = cam[4], c = cam[8], d = cam[1], e = cam[5], f = cam[9], g = cam[2], h = cam[6], i = cam[10];
         const double co00 = e * i - f * h, co01 = -(d * i - f * g), co02 = d * h - e * g;
@@ -897,7 +905,7 @@ extern "C" int rt_get_counters_detail(rt_ctx *ctx, rt_counters_detail *out)
     if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_get_counters_detail: null argument");
     if (!ctx->counted) return fail(RT_ERR_INVALID, "rt_get_counters_detail: the last render was not done with RT_FLAG_COUNT");
     if (ctx->cfg.flags & RT_FLAG_SIMPLE) return fail(RT_ERR_INVALID, "rt_get_counters_detail: the simple kernel does not split its counters");
-    unsigned long long h[19];
+    unsigned long long h[20];
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipDeviceSynchronize());
     RT_HIP(hipMemcpy(h, ctx->d_counters + 32, sizeof(h), hipMemcpyDeviceToHost));
@@ -908,6 +916,7 @@ extern "C" int rt_get_counters_detail(rt_ctx *ctx, rt_counters_detail *out)
     out->shadow_rays_traced = h[16];
     out->hit_lights_shaded = h[17];
     out->primary_rays_formed = h[18];
+    out->cubic_points = h[19];
     return RT_OK;
 }
 

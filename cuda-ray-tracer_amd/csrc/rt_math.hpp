@@ -284,6 +284,87 @@ __device__ __forceinline__ double intersect_cubic_branch(const double *c, double
     return solve_quadlin(t2, t1, t0);
 }
 
+// ---- degree-3 surfaces: F(o + t d) as a Taylor polynomial around the ray origin ----
+// The reference expands F(o + t d) term by term for every (ray, object) pair (include/surface_impl.h:44-103: 286 operations).
+// The same polynomial in t is
+//     t0 = F(o),   t1 = grad F(o) . d,   t2 = 1/2 d^T H(o) d,   t3 = C(d)   (C = the cubic form of the degree-3 terms),
+// and most of that does not depend on the ray at hand: F, grad F and H at the camera origin are constants of the frame for all primary
+// rays; at a hit's shadow-ray origin they are the same for every light.  What is left per test is a dot product, a quadratic form and
+// (where the direction differs per lane) the cubic form: ~50 operations instead of 286, ~16 for a directional light.
+// Degree-3 scenes are held to 1e-5 relative, not to bit-identity (device cbrt / acos / cos already differ from glibc's in the last
+// place), so the re-association is admissible; the flip statistics of tests/ and tests/tools/fuzz_cubic.py bound its effect.
+struct CubicAt {
+    double f;                          // F(o)
+    double gx, gy, gz;                 // grad F(o)
+    double hxx, hyy, hzz, hxy, hxz, hyz; // 1/2 d2F/dx2 ..., d2F/dxdy ...: t2 = hxx dx^2 + hyy dy^2 + hzz dz^2 + hxy dx dy + hxz dx dz + hyz dy dz
+};
+
+__host__ __device__ __forceinline__ CubicAt cubic_at(const double *__restrict__ c, const D3 &o)
+{
+    const double x = o.x, y = o.y, z = o.z;
+    CubicAt a;
+    // second derivatives: linear in o
+    a.hxx = ((3.0 * c[K_X3]) * x + c[K_X2Y] * y) + (c[K_X2Z] * z + c[K_X2]);
+    a.hyy = ((3.0 * c[K_Y3]) * y + c[K_XY2] * x) + (c[K_Y2Z] * z + c[K_Y2]);
+    a.hzz = ((3.0 * c[K_Z3]) * z + c[K_XZ2] * x) + (c[K_YZ2] * y + c[K_Z2]);
+    a.hxy = ((2.0 * c[K_X2Y]) * x + (2.0 * c[K_XY2]) * y) + (c[K_XYZ] * z + c[K_XY]);
+    a.hxz = ((2.0 * c[K_X2Z]) * x + (2.0 * c[K_XZ2]) * z) + (c[K_XYZ] * y + c[K_XZ]);
+    a.hyz = ((2.0 * c[K_Y2Z]) * y + (2.0 * c[K_YZ2]) * z) + (c[K_XYZ] * x + c[K_YZ]);
+    // gradient: dF/dx = x (3 x3 x + 2 x2y y + 2 x2z z + 2 x2) + y (xy2 y + xyz z + xy) + z (xz2 z + xz) + kx, and cyclically
+    a.gx = (x * (((3.0 * c[K_X3]) * x + (2.0 * c[K_X2Y]) * y) + ((2.0 * c[K_X2Z]) * z + 2.0 * c[K_X2])) + y * ((c[K_XY2] * y + c[K_XYZ] * z) + c[K_XY])) + (z * (c[K_XZ2] * z + c[K_XZ]) + c[K_X]);
+    a.gy = (y * (((3.0 * c[K_Y3]) * y + (2.0 * c[K_XY2]) * x) + ((2.0 * c[K_Y2Z]) * z + 2.0 * c[K_Y2])) + x * ((c[K_X2Y] * x + c[K_XYZ] * z) + c[K_XY])) + (z * (c[K_YZ2] * z + c[K_YZ]) + c[K_Y]);
+    a.gz = (z * (((3.0 * c[K_Z3]) * z + (2.0 * c[K_XZ2]) * x) + ((2.0 * c[K_YZ2]) * y + 2.0 * c[K_Z2])) + x * ((c[K_X2Z] * x + c[K_XYZ] * y) + c[K_XZ])) + (y * (c[K_Y2Z] * y + c[K_YZ]) + c[K_Z]);
+    // F(o), grouped by the leading variable
+    const double fx = x * (x * ((c[K_X3] * x + c[K_X2Y] * y) + (c[K_X2Z] * z + c[K_X2])) + ((y * ((c[K_XY2] * y + c[K_XYZ] * z) + c[K_XY]) + z * (c[K_XZ2] * z + c[K_XZ])) + c[K_X]));
+    const double fy = y * (y * ((c[K_Y3] * y + c[K_Y2Z] * z) + c[K_Y2]) + (z * (c[K_YZ2] * z + c[K_YZ]) + c[K_Y]));
+    const double fz = z * (z * (c[K_Z3] * z + c[K_Z2]) + c[K_Z]);
+    a.f = (fx + fy) + (fz + c[K_C]);
+    return a;
+}
+
+// t3 .. t0 of the ray (o, d) from the surface's Taylor data at o and the direction.
+__device__ __forceinline__ void cubic_coefs(const double *__restrict__ c, const CubicAt &a, const D3 &d, double &t3, double &t2, double &t1, double &t0)
+{
+    const double dxx = d.x * d.x, dyy = d.y * d.y, dzz = d.z * d.z, dxy = d.x * d.y, dxz = d.x * d.z, dyz = d.y * d.z;
+    t0 = a.f;
+    t1 = (a.gx * d.x + a.gy * d.y) + a.gz * d.z;
+    t2 = ((a.hxx * dxx + a.hyy * dyy) + (a.hzz * dzz + a.hxy * dxy)) + (a.hxz * dxz + a.hyz * dyz);
+    t3 = (((c[K_X3] * dxx + c[K_XY2] * dyy) + (c[K_XZ2] * dzz + c[K_XYZ] * dyz)) * d.x + ((c[K_Y3] * dyy + c[K_X2Y] * dxx) + c[K_YZ2] * dzz) * d.y) +
+         ((c[K_Z3] * dzz + c[K_X2Z] * dxx) + c[K_Y2Z] * dyy) * d.z;
+}
+
+// Root of the reference's solver for a degree-3 surface, from the Taylor data (kept out of line like intersect_cubic; the data by value,
+// in registers: a pointer to it would put it in scratch memory).
+__device__ __noinline__ double intersect_cubic_at(const double *c, double f, double gx, double gy, double gz, double hxx, double hyy, double hzz, double hxy, double hxz,
+                                                  double hyz, double dx, double dy, double dz)
+{
+    const CubicAt a{f, gx, gy, gz, hxx, hyy, hzz, hxy, hxz, hyz};
+    double t3, t2, t1, t0;
+    cubic_coefs(c, a, D3{dx, dy, dz}, t3, t2, t1, t0);
+    if (fabs(t3) > EPS) return solve_cubic(t3, t2, t1, t0);
+    return solve_quadlin(t2, t1, t0);
+}
+__device__ __forceinline__ double intersect_cubic_at(const double *c, const CubicAt &a, const D3 &d)
+{
+    return intersect_cubic_at(c, a.f, a.gx, a.gy, a.gz, a.hxx, a.hyy, a.hzz, a.hxy, a.hxz, a.hyz, d.x, d.y, d.z);
+}
+
+// The same value, inlined, also naming the solver branch that produced it (counting builds only): 0 Cardano, 1 trigonometric, 2 quadratic, 3 linear / constant.
+__device__ __forceinline__ double intersect_cubic_at_branch(const double *c, const CubicAt &a, const D3 &d, int &branch)
+{
+    double t3, t2, t1, t0;
+    cubic_coefs(c, a, d, t3, t2, t1, t0);
+    if (fabs(t3) > EPS) {
+        const double a2 = t2 / t3, a1 = t1 / t3, a0 = t0 / t3; // the first lines of solve_cubic, to see which way it goes
+        const double q = (3.0 * a1 - a2 * a2) / 9.0;
+        const double r = (9.0 * a2 * a1 - 27.0 * a0 - 2.0 * a2 * a2 * a2) / 54.0;
+        branch = (q * q * q + r * r > 0) ? 0 : 1;
+        return solve_cubic(t3, t2, t1, t0);
+    }
+    branch = fabs(t2) > EPS ? 2 : 3;
+    return solve_quadlin(t2, t1, t0);
+}
+
 // intersect_ray, include/surface_impl.h:21-155: parameter of the root the reference would return.
 __device__ __forceinline__ double intersect(const double *__restrict__ c, uint32_t cls, const Mono &m)
 {

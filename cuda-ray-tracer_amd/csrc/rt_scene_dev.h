@@ -162,9 +162,13 @@ struct FrameArgs {
     uint32_t frame_tag;   // unique per frame of this context, never 0, < 2^29
     uint32_t n_scan;      // classifying workgroups in this launch
     uint32_t lean;        // 1: all-sphere scene without mirrors, dense output: the wave-per-block instantiation renders it (rt_wavefront.hip, "the lean path")
+    // Degree-3 surfaces: F, grad F and the half Hessian of the first RT_CUB_AT_MAX of them at the ray origin of the frame (rtm::CubicAt, ten
+    // doubles each) -- constants of all primary rays, set per frame by rt_render (further cubic objects are evaluated by the kernel)
+    double cub_at[4][10];
     uint32_t pt_mask[2];  // lean path: bit l = light l is a point light (at most 64 lights there; scenes with more take the general instantiation)
 };
 
+#define RT_CUB_AT_MAX 4    // FrameArgs::cub_at
 #define RT_TILE 16        // a workgroup renders a 16 x 16 pixel tile
 #define RT_SCAN_TILES 64  // tiles classified by one classifying workgroup: sixteen per wave
 #define RT_PAINT_TILES 16 // tiles one paint workgroup is responsible for: four per wave

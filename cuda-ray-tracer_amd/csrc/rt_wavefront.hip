@@ -153,9 +153,10 @@ constexpr int wf_occupancy()
 //             39-43 culling: tile pyramid, primary cone, shadow phase directional / point light, records formed
 //             44-47 cubic tests by solver branch   48 shadow rays traced (of counters[1] considered)   49 hits shaded per light
 //             50 primary rays formed (pixels of the tiles that are traced; counters[0] counts every pixel, as the reference does)
+//             51 Taylor data of a degree-3 surface formed at a ray origin (lanes)
 enum { K_US = 0, K_GQ = 1, K_LIN = 2, K_CUB = 3 };
 enum { C_TILE = 0, C_PRIMARY = 1, C_SHADOW_DIR = 2, C_SHADOW_SPH = 3, C_RECORDS = 4 };
-constexpr int N_CNT_W = 19;
+constexpr int N_CNT_W = 20;
 template <bool COUNT>
 struct Cnt {
     __device__ __forceinline__ void add(int, unsigned long long = 1) {}
@@ -166,12 +167,13 @@ struct Cnt {
     __device__ __forceinline__ void traced() {}
     __device__ __forceinline__ void shaded() {}
     __device__ __forceinline__ void primary_traced() {}
+    __device__ __forceinline__ void cubic_point() {}
     __device__ __forceinline__ void flush(unsigned long long *) {}
 };
 template <>
 struct Cnt<true> {
     unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t w[N_CNT_W] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // per thread and frame: 32 bits are plenty
+    uint32_t w[N_CNT_W] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // per thread and frame: 32 bits are plenty
     __device__ __forceinline__ void add(int i, unsigned long long n = 1) { v[i] += n; }
     __device__ __forceinline__ void exec(int cls, unsigned long long n) { v[6] += n; w[cls] += (uint32_t) n; }
     __device__ __forceinline__ void solve(int cls) { v[5] += 1; w[4 + cls] += 1; }
@@ -185,6 +187,7 @@ struct Cnt<true> {
     __device__ __forceinline__ void traced() { w[16] += 1; }
     __device__ __forceinline__ void shaded() { w[17] += 1; }
     __device__ __forceinline__ void primary_traced() { w[18] += 1; }
+    __device__ __forceinline__ void cubic_point() { w[19] += 1; } // Taylor data of a degree-3 surface formed at a ray origin (rt_math.hpp, cubic_at)
     __device__ __forceinline__ void flush(unsigned long long *g)
     {
         for (int i = 0; i < 8; i++)
@@ -597,7 +600,28 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
         for (uint32_t j = 0; j < fa.n_cub; j++) {
             const uint32_t k = __builtin_amdgcn_readfirstlane(S.cub[j]);
             if (live) {
+                // F(o + t d) from the surface's Taylor data at the ray origin (rt_math.hpp, CubicAt): for primary rays the origin is the
+                // frame's, and rt_render has evaluated the data of the first RT_CUB_AT_MAX degree-3 objects there (uniform: scalar loads)
                 double t;
+#if RT_FAST
+                // (FMA build only: the strict build keeps the reference's expansion, term by term -- the re-association flips 0.1 % of the
+                // pixels of scenes/cayley.yml across a solver discontinuity, more than two CPU builds of the reference differ by, and buys 2 %)
+                CubicAt ca;
+                if (PRIMARY && j < RT_CUB_AT_MAX) {
+                    const double *q = fa.cub_at[j];
+                    ca = CubicAt{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9]};
+                } else {
+                    ca = cubic_at(gobj[k].c, m.o);
+                    cnt.cubic_point();
+                }
+                if (COUNT) { // counting builds also report which solver branch ran (flop accounting of bench.py)
+                    int br;
+                    t = intersect_cubic_at_branch(gobj[k].c, ca, m.d, br);
+                    cnt.cubic(br);
+                } else {
+                    t = intersect_cubic_at(gobj[k].c, ca, m.d);
+                }
+#else
                 if (COUNT) { // counting builds also report which solver branch ran (flop accounting of bench.py)
                     int br;
                     t = intersect_cubic_branch(gobj[k].c, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, br);
@@ -605,6 +629,7 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
                 } else {
                     t = intersect_cubic(gobj[k].c, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z);
                 }
+#endif
                 accept(t, (int) k, best_t, best);
             }
         }
@@ -673,7 +698,7 @@ constexpr int NO_BLOCKER = 0x7fffffff;
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool SPHERICAL, bool OWN = false, typename Light = DevLight> // SPHERICAL: the light's kind -- one copy of the loop per kind, each without the other's code
 __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj,
                                               const Mono &sm, double max_t, bool valid, bool prod, const Ball *ballp, const BoxH *boxp, const CullRec *crec, const Light &lt,
-                                              uint32_t lane, Cnt<COUNT> &cnt, uint32_t own = 0, bool own_skip = false, unsigned long long own_excl = 0ull)
+                                              uint32_t lane, Cnt<COUNT> &cnt, uint32_t own = 0, bool own_skip = false, unsigned long long own_excl = 0ull, const CubicAt *ca0 = nullptr)
 {
     // valid: lanes whose ray is tested.  prod: lanes the product build tests (== valid there); a counting build tests more lanes --
     // all that have a hit -- and counts executed work for the `prod` ones only (wave-level work: if any lane is one).
@@ -775,7 +800,26 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
         for (uint32_t j = 0; j < fa.n_cub; j++) {
             const uint32_t k = __builtin_amdgcn_readfirstlane(S.cub[j]);
             if (valid && (int) k < blocker && (COUNT || blocker == NO_BLOCKER)) {
+                // the surface's Taylor data at the shadow-ray origin: the same for every light, so the caller forms it once per chunk for
+                // the scene's first degree-3 object (ca0); further ones are evaluated here
                 double t;
+#if RT_FAST
+                CubicAt ca;
+                if (j == 0 && ca0) {
+                    ca = *ca0;
+                } else {
+                    ca = cubic_at(gobj[k].c, sm.o);
+                    if (prod) cnt.cubic_point();
+                }
+                if (COUNT) {
+                    int br;
+                    t = intersect_cubic_at_branch(gobj[k].c, ca, sm.d, br);
+                    cnt.cubic(br, prod);
+                } else {
+                    t = intersect_cubic_at(gobj[k].c, ca, sm.d);
+                }
+#else
+                (void) ca0;
                 if (COUNT) {
                     int br;
                     t = intersect_cubic_branch(gobj[k].c, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z, br);
@@ -783,6 +827,7 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
                 } else {
                     t = intersect_cubic(gobj[k].c, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z);
                 }
+#endif
                 if (t > EPS && t < max_t) blocker = (int) k;
             }
         }
@@ -1599,6 +1644,13 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 const uint32_t own = (hinfo_b >> 8) & 0x7FFFFFu;
                 const bool own_ok = OWNG && valid && (hinfo_b >> 31) != 0u && fa.n_us == fa.n_obj;
                 const CullRec *my_crec = reinterpret_cast<const CullRec *>(smem + (L.crec + c * L.n_crec * (uint32_t) sizeof(CullRec)));
+                // degree-3 scenes, FMA build: the first such object's Taylor data at this hit's shadow-ray origin, once for all the lights this wave takes
+                CubicAt ca0{};
+                const bool have_ca0 = RT_FAST && HAS_CUBIC && fa.n_cub != 0u && ((wave + 4u - (c & 3u)) & 3u) < fa.n_lights; // (FMA build only: see nearest())
+                if (have_ca0) {
+                    ca0 = cubic_at(gobj[__builtin_amdgcn_readfirstlane(S.cub[0])].c, sm.o);
+                    if (valid) cnt.cubic_point();
+                }
                 for (uint32_t l = (wave + 4u - (c & 3u)) & 3u; l < fa.n_lights; l += 4) {
                     // the light through the constant address space (LightK, rt_scene_dev.h): scalar loads, its fields in SGPRs; one body per
                     // light kind, nothing merged between them
@@ -1626,7 +1678,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                             mono_set_od<NEED_CROSS>(sd);
                             if (wanted) cnt.traced();
                             const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, false, OWNG>(fa, S, gobj, sd, 1e6, COUNT ? valid : wanted, wanted, sball + c, sbox + c, my_crec, lk, lane, cnt,
-                                                                                                      own, own_ok && bfe && quad_l && wanted, 0ull);
+                                                                                                      own, own_ok && bfe && quad_l && wanted, 0ull, have_ca0 ? &ca0 : nullptr);
                             // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
                             if (valid) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
                             skip |= __ballot(valid && blocker != NO_BLOCKER);
@@ -1649,7 +1701,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                             mono_set_d<NEED_CROSS>(sd, D3{(double) (float) dx, (double) (float) dy, (double) (float) dz});
                             mono_set_od<NEED_CROSS>(sd);
                             if (wanted) cnt.traced();
-                            const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, true, OWNG>(fa, S, gobj, sd, 1.0, COUNT ? valid : wanted, wanted, sball + c, sbox + c, my_crec, lk, lane, cnt);
+                            const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, true, OWNG>(fa, S, gobj, sd, 1.0, COUNT ? valid : wanted, wanted, sball + c, sbox + c, my_crec, lk, lane, cnt,
+                                                                                                     0u, false, 0ull, have_ca0 ? &ca0 : nullptr);
                             if (valid) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
                             skip = __ballot(valid && blocker != NO_BLOCKER);
                         } else if (COUNT && valid) {

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 #define RT_ABI_DIAGNOSTIC 0x4000 /* set in rt_abi_version() of a library built with STAMPS / DEBUG_EXITS / SPILLS_OK / ...: for
                                     measurements only (it may spill registers to scratch, which the product never does) */
 
@@ -120,6 +120,8 @@ typedef struct rt_counters_detail {
     uint64_t shadow_rays_traced; /* of rt_counters.shadow_rays: those not skipped because the hit faces away from the light */
     uint64_t hit_lights_shaded;  /* surface_color evaluations (light_impl.h:29) */
     uint64_t primary_rays_formed; /* pixels of the tiles that are actually traced (rt_counters.primary_rays counts every pixel) */
+    uint64_t cubic_points;        /* (ABI 3) degree-3 surfaces: evaluations of F, grad F and the half Hessian at a ray origin (lanes); the data
+                                   * of the frame's own origin comes from the host and is not counted */
 } rt_counters_detail;
 
 typedef struct rt_ctx rt_ctx;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(pkg):
     multi = ctypes.CDLL(pkg.MULTI_LIB_PATH)
     for name in declared_functions():
         assert hasattr(multi if name in pkg.MULTI_ABI_SYMBOLS else lib, name), name
-    assert lib.rt_abi_version() == 2
+    assert lib.rt_abi_version() == 3
     needed = subprocess.run(["readelf", "-d", pkg.MULTI_LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "librccl" in needed and "libmi355rt.so" in needed
     base = subprocess.run(["readelf", "-d", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout

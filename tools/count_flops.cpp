@@ -103,7 +103,12 @@ int main()
     const long test_quadric = ops([&] { g_sink = needs_solve(gq_t2(gq, mc), gq_t1(gq, mc), gq_t0(gq, mc)); });
     const long test_linear = ops([&] { Counted t1 = lin_t1(lin, m), t0 = lin_t0(lin, m); g_sink = t1 > t0; });
     Counted t3, t2, t1, t0;
-    const long test_cubic_expand = ops([&] { Mono mm; make_mono(mm, o, d); cubic_poly(cub, mm, t3, t2, t1, t0); });
+    // degree-3 surfaces: t3 .. t0 from the surface's Taylor data at the ray origin and the direction (rt_math.hpp, cubic_coefs), and
+    // forming that data at a point (cubic_at) -- which happens once per (hit, wave that takes lights of its chunk), not per test
+    CubicAt cat;
+    const long cubic_point = ops([&] { cat = cubic_at(cub, o); });
+    const long test_cubic_expand = ops([&] { cubic_coefs(cub, cat, d, t3, t2, t1, t0); });
+    const long test_cubic_dense = ops([&] { Mono mm; make_mono(mm, o, d); cubic_poly(cub, mm, t3, t2, t1, t0); }); // (the reference's expansion, term by term: the strict build)
     // --- root solves.  The deferred solve re-forms the coefficients from the table entry (second pass over the few candidates).
     auto quad_first = [&] { return ops([&] { g_sink = solve_quadlin(1.0, -10.0, 9.0) > 0.0; }); };   // first root accepted
     auto quad_second = [&] { return ops([&] { g_sink = solve_quadlin(1.0, 10.0, -9.0) > 0.0; }); };  // first root < EPS: second division
@@ -162,7 +167,8 @@ int main()
 
     std::printf("{\n \"source\": \"tools/count_flops.cpp: the kernel's math headers (rt_math.hpp, rt_wavefront_math.hpp) executed over an operation-counting scalar; "
                 "add / sub / mul / div / sqrt = 1 each, no FMA (strict build), comparisons / negation / fabs / conversions free\",\n \"units\": {\n");
-    std::printf("  \"test_unitsq\": %ld,\n  \"test_quadric\": %ld,\n  \"test_linear\": %ld,\n  \"test_cubic_expand\": %ld,\n", test_unitsq, test_quadric, test_linear, test_cubic_expand);
+    std::printf("  \"test_unitsq\": %ld,\n  \"test_quadric\": %ld,\n  \"test_linear\": %ld,\n  \"test_cubic_expand\": %ld,\n  \"cubic_point\": %ld,\n  \"test_cubic_dense\": %ld,\n", test_unitsq, test_quadric, test_linear,
+                test_cubic_expand, cubic_point, test_cubic_dense);
     std::printf("  \"solve_unitsq\": %.1f,\n  \"solve_quadric\": %.1f,\n  \"solve_linear\": %ld,\n", recompute_us + solve_quadlin_mean, recompute_gq + solve_quadlin_mean, solve_linear);
     std::printf("  \"cubic_cardano\": %ld,\n  \"cubic_trig\": %ld,\n  \"cubic_quadratic\": %.1f,\n  \"cubic_linear\": %ld,\n", solve_cardano, solve_trig, solve_quadlin_mean, solve_linear);
     std::printf("  \"tile_planes\": %ld,\n", tile_planes_ops);

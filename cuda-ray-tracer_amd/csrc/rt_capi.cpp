@@ -521,6 +521,7 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
         for (uint32_t k = 0; k < sd->n_objects * 3u && finite; k++) finite = std::isfinite(sd->albedo[k]);
         l.backface_exact = (!l.spherical && finite) ? 1u : 0u;
     }
+    fa.lights_plain = 1u;
     std::vector<LightK> lightk(sd->n_lights); // the same lights as the lean path reads them (rt_scene_dev.h)
     for (uint32_t i = 0; i < sd->n_lights; i++) {
         const DevLight &l = lights[i];
@@ -533,6 +534,7 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
         k.s_xz = std::fabs(l.sdir[0]) + std::fabs(l.sdir[2]);
         k.s_xy = std::fabs(l.sdir[0]) + std::fabs(l.sdir[1]);
         k.flags = (l.spherical ? 1u : 0u) | (l.backface_exact ? 2u : 0u) | (std::fabs(l.u2) > 1e-7 ? 4u : 0u); // EPS of include/surface_impl.h:16,138
+        if (!l.spherical && (k.flags & 6u) != 6u) fa.lights_plain = 0u;
     }
 
     // the wave-per-block instantiation: unit spheres only, every one with a bounding radius, no mirror (sparse frames take the other one)

@@ -165,6 +165,7 @@ struct FrameArgs {
     // Degree-3 surfaces: F, grad F and the half Hessian of the first RT_CUB_AT_MAX of them at the ray origin of the frame (rtm::CubicAt, ten
     // doubles each) -- constants of all primary rays, set per frame by rt_render (further cubic objects are evaluated by the kernel)
     double cub_at[4][10];
+    uint32_t lights_plain; // lean path: every directional light has flags 2 and 4 of LightK (finite colours, |sdir|^2 > EPS): the specialised light loop applies
     uint32_t pt_mask[2];  // lean path: bit l = light l is a point light (at most 64 lights there; scenes with more take the general instantiation)
 };
 

@@ -1045,6 +1045,35 @@ __device__ __forceinline__ void lean_block(const FrameArgs &fa, const SceneLds &
                 const MatEntry mt = S.mat[bi];
                 const F3 aop{mt.albedo[0] / PI_F, mt.albedo[1] / PI_F, mt.albedo[2] / PI_F}; // object_color / pi, once per hit
                 F3 acc{0.0f, 0.0f, 0.0f};
+                if (!COUNT && fa.lights_plain && fa.n_us <= 64u) { // launch-uniform: product build, every directional light has finite colours and |d|^2 > EPS
+                    // The loop below (which handles every combination) specialised: no per-light flags to look at, the light-behind-the-surface
+                    // test straight out of one compare (lanes without a hit carry a zero normal: (float) dot = 0, not in front), the shadow test in
+                    // lean_dir_blocked.  Same values, same order.
+                    const D3 snz{hit ? sn.x : 0.0, hit ? sn.y : 0.0, hit ? sn.z : 0.0};
+                    for (uint32_t l = 0; l < fa.n_lights; l++) {
+                        RT_LOAD_LIGHTK(lk, l)
+                        if (!((pt_mask >> l) & 1ull)) { // directional: include/light_impl.h:23-25
+                            const float lam = (float) dot3(snz, D3{lk.p[0], lk.p[1], lk.p[2]}); // surface_color's (float) dot(n, dir), include/light_impl.h:42
+                            const bool wanted = 0.0f < lam; // a light behind the surface adds exactly +0, shadowed or not: such lanes sit the light out
+                            if (__any(wanted)) {
+                                const bool blocked = lean_dir_blocked(S.us, my_crec, my_box, sm.o, sm.u0, lk, wanted, bi, skip_geom, own_all, fa.n_us, lane);
+                                if (wanted && !blocked) { // ((albedo / pi) * colour) * max(0, n.l), left to right (include/light_impl.h:43); max(0, lam) = lam here
+                                    acc.x += aop.x * lk.color[0] * lam;
+                                    acc.y += aop.y * lk.color[1] * lam;
+                                    acc.z += aop.z * lk.color[2] * lam;
+                                }
+                            }
+                        } else if (hit && !((pt_blocked >> l) & 1ull)) { // point light, not blocked
+                            const D3 spl{hp[tid], hp[M.hp_stride + tid], hp[2 * M.hp_stride + tid]};
+                            const double lp[3] = {lk.p[0], lk.p[1], lk.p[2]};
+                            const float lc[3] = {lk.color[0], lk.color[1], lk.color[2]};
+                            const F3 col = surface_color_pre(lp, lc, true, spl, sn, aop);
+                            acc.x += col.x;
+                            acc.y += col.y;
+                            acc.z += col.z;
+                        }
+                    }
+                } else
                 for (uint32_t l = 0; l < fa.n_lights; l++) {
                     RT_LOAD_LIGHTK(lk, l)
                     if (hit) cnt.add(1);

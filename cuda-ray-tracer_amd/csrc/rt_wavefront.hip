@@ -1366,7 +1366,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             }
             if (lane == 0) { s_decode[0] = d_tile; s_decode[1] = d_flags; s_decode[2] = oh.cost_max; s_half[0] = d_half; }
         }
+        if (LEAN) RT_STAMP(3); // (lean path, stamped builds: set-up split into "until the decode barrier", ...
         lds_barrier();
+        if (LEAN) RT_STAMP(4); // ... "waiting at it", ...
         tile = (uint32_t) __builtin_amdgcn_readfirstlane((int) s_decode[0]);
         const uint32_t d_flags = (uint32_t) __builtin_amdgcn_readfirstlane((int) s_decode[1]);
         cost_scale = (uint32_t) __builtin_amdgcn_readfirstlane((int) s_decode[2]);
@@ -1495,7 +1497,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             for (uint32_t i = tid + 2 * WG; i < tot16; i += WG) dst[i] = i < n16 ? stage_scene[i] : stage_light[i - n16];
             staged = true;
             if (LEAN && tid == 0) { s_done[0] = 0u; s_cost[0] = 0u; s_zero[0] = 0u; if (!(hot_flags & 2u)) s_half[0] = 0u; }
+            if (LEAN) RT_STAMP(7); // ... "tile known -> staging loads back and written", ...
             lds_barrier();
+            if (LEAN) RT_STAMP(8); // ... "staging barrier"; phase 1 is then the camera-table reads and the primary direction)
         }
         bool live = inside; // this pixel still has a ray to trace
         uint32_t ord_cls = 0, ord_pos = 0; // one thread per tile with hits: the tile's entry in the next frame's launch order

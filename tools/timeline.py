@@ -46,6 +46,9 @@ for t in np.arange(0.0, end.max() + step, step):
     print(f"{t:8.1f} {a:8d} {b:8d}   {'#' * (a // 100)}{'.' * (b // 100)}")
 names = ["stage scene->LDS", "setup/primary dir", "A nearest", "A normal+compact", "barrier after A", "A' balls + barrier",
          "B shadow items", "barrier after B", "C shade", "D blend + barrier", "store", "classify / paint"]
+if os.environ.get("TIMELINE_LEAN_NAMES"):   # the lean instantiation stamps its set-up in pieces (slots 3, 4, 7, 8)
+    names[3], names[4], names[7], names[8] = "setup: args + launch-order decode", "setup: decode barrier", "setup: tile -> staging written", "setup: staging barrier"
+    names[1] = "setup: camera tables + primary dir"
 tot = rows[:, :12].sum()
 for i, n in enumerate(names):
     print(f"  {n:22s} {int(rows[:, i].sum()):14d}  {100.0 * rows[:, i].sum() / max(tot, 1):5.1f} %")

@@ -16,15 +16,15 @@
 //                    DEFERRED to a short per-lane loop over the few objects that can hit (a 64-bit candidate mask
 //                    per lane).  Hits are compacted into an LDS queue (ballot prefix + per-wave counts).
 //                    A tile whose round finds no hit at all stops here: one barrier, store, done.
-//   A' hits          first round with hits: stage the scene + lights into LDS.  Per 64-hit chunk: bounding ball of
-//                    the chunk's hit points (DPP min/max reductions).
+//   A' hits          per 64-hit chunk: bounding box of the chunk's hit points (six FP32 DPP reductions, rounded outwards), its
+//                    ball, and a culling record per sphere (the light-independent half of the shadow-phase culling).
 //   B  shadow rays   every wave visits every chunk and takes the lights == (wave - chunk) mod 4.  Per (chunk,
 //                    light) the wave first CULLS: lane j decides whether sphere j can possibly touch any shadow ray
 //                    of the chunk (distance of its centre to the chunk's swept bounding volume, with a generous
 //                    margin -- purely conservative, see relevant_mask); the ballot of that is a wave-uniform object
-//                    mask.  Then the same two-step test as in A over the surviving objects only.  One bit per
-//                    (hit, light) in LDS.
-//   C  shading       one lane per hit: lights in order, Lambert term for the unshadowed ones, FP32 accumulate,
+//                    mask.  Then the same two-step test as in A over the surviving objects only -- except the hit's own
+//                    sphere where the own-sphere rule applies.  One 64-bit mask per (chunk, light) in LDS.
+//   C  shading       wave c shades chunk c, one lane per hit: lights in order, Lambert term for the unshadowed ones, FP32 accumulate,
 //                    clamp (src/update-cpu.cpp:57-78).
 //   D  blend/bounce  the pixel's owner lane blends the colour into its running result and, for mirrors, sets
 //                    up the next round's ray (src/update-cpu.cpp:96-117).  One flag per wave + one barrier tell
@@ -32,17 +32,27 @@
 //
 //   Every lane finally stores its pixel (16-byte RGBA32F or 4-byte RGBA8, rows of the tile contiguous).
 //
-//   Tiles are started heaviest first: each tile reports its round-0 hit count (four classes) into per-class lists, and
-//   the NEXT frame's grid begins with one slot per listed tile before the index-order slots (temporal coherence of an
-//   interactive camera; a stale list only costs time).  4-14 % on a static camera, 2-6 % on a moving one.
+//   That is the GENERAL schedule (template argument LEAN = false): scenes with planes, general quadrics, degree-3 surfaces or
+//   mirrors, counting renders, sparse output, and all-sphere views in which the tiles with hits do not fill the GPU (there the
+//   costliest tiles are split into half tiles and the lights of a chunk are spread over the workgroup's four waves).
+//   The LEAN schedule (LEAN = true, lean_block below) is what an all-sphere scene without mirrors runs while its tiles with hits
+//   fill the GPU: every wave keeps its own 8x8 block from the primary ray to the store -- hits stay in their pixel's lane (no
+//   queue, no compaction), the lights are visited in order and shaded on the spot (no shadow masks, no phase C), and after the
+//   staging barrier the workgroup never synchronises again.  rt_capi.cpp chooses between the two per frame from the previous
+//   frame's census.
 //
-// Scene data (rt_scene_dev.h: object records + one packed table per surface class + lights) is read straight from
-// global memory in round 0 -- wave-uniform indices become scalar loads, and 83 % of the tiles of a typical frame never
-// need more than that -- and from an LDS copy afterwards: unconditional LDS broadcast reads for wave-uniform loops
-// (LDS returns in order, so unrolled iterations overlap reads with arithmetic), per-lane gathers for deferred solves,
-// normals and albedo.  The kernel is instantiated per scene feature (general quadrics, degree-3 surfaces, mirrors):
-// an instantiation contains no code and no registers for a feature the scene does not have; the mirror-free
-// sphere/plane one fits 94 VGPRs (5 waves per SIMD).  DESIGN.md section 5 has the measurements behind each choice.
+//   One launch renders the frame: classify workgroups decide a word per tile (empty / has hits / rendered by a list slot),
+//   list slots render the tiles that had hits in the previous frame, costliest first (16 cost classes, dealt out in a snake over
+//   the CUs; cost = what the tile's waves spent on their lights, two s_memtime reads), paint workgroups fill the empty tiles in
+//   bulk, and index slots (one per tile) leave after one load unless their tile has hits that no list slot covers (temporal
+//   coherence of an interactive camera; a stale list only costs time, never a pixel).
+//
+// Scene data (rt_scene_dev.h): the per-class tables are staged into LDS by every workgroup that traces (wave-uniform loops read
+// them as LDS broadcasts, deferred solves / normals / albedo gather per lane); the lights are never staged -- the LightK table is
+// read through the constant address space, so a light's constants are scalar loads into SGPRs.  The kernel is instantiated per
+// scene feature (general quadrics, degree-3 surfaces, mirrors, lean): an instantiation contains no code and no registers for a
+// feature the scene does not have.  The sphere instantiations fit 80 VGPRs (six workgroups per CU); no instantiation spills
+// VGPRs or has a private segment (make refuses to link otherwise).  DESIGN.md section 5 has the measurements behind each choice.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 

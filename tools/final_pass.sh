@@ -27,7 +27,7 @@ step 600 $O/pmc.log "bash tools/pmc_profile.sh $O/pmc"
 step 60 $O/pmc_summary.txt "python tools/pmc_summarize.py $O/pmc"
 step 300 $O/kt4.log "cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/kt4 -- python3 $GRAFT_REPO_ROOT/bench.py --workload config4 --steps 50 --warmup 5 --no-cpu-baseline --no-orbit --no-configs > $GRAFT_REPO_ROOT/$O/bench_config4_under_rocprof.json"
 step 600 $O/pmc4.log "BENCH_ARGS='--workload config4' bash tools/pmc_profile.sh $O/pmc4"
-step 60 $O/pmc4_summary.txt "python tools/pmc_summarize.py $O/pmc4 'wavefront_tile_kernel<false'"
+step 60 $O/pmc4_summary.txt "BENCH_ARGS='--workload config4' python tools/pmc_summarize.py $O/pmc4 'wavefront_tile_kernel<false'"
 step 60 $O/cleanup.txt "find $O/pmc $O/pmc4 $O/kt $O/kt4 -name '*.csv' -size +1M -delete; find $O -name '*.db' -delete"
 fi
 if [ "${PART:-1}" = 3 ]; then

@@ -23,7 +23,11 @@ for _ in range(3):
 d = r.debug_counters()[8:20]
 names = ["stage scene->LDS", "setup/primary dir", "A nearest", "A normal+compact", "barrier after A", "A' balls + barrier",
          "B shadow items", "barrier after B", "C shade", "D blend + barrier", "store", "-"]
+if os.environ.get("TIMELINE_LEAN_NAMES") or os.environ.get("MI355RT_LEAN") == "always":   # the lean instantiation stamps its set-up in pieces (slots 3, 4, 7, 8)
+    names[3], names[4], names[7], names[8] = "setup: args + launch-order decode", "setup: decode barrier", "setup: tile -> staging written", "setup: staging barrier"
+    names[1] = "setup: camera tables + primary dir"
+    names[11] = "classify / paint / index slots"
 tot = sum(d)
 print(f"{name} {W}x{H} flags={flags}: kernel {ms*1e3:.1f} us (stamped build); total wave-cycles {tot:.3e}")
 for n, v in zip(names, d):
-    print(f"  {n:22s} {v:14d}  {100.0*v/max(tot,1):5.1f} %")
+    print(f"  {n:36s} {v:14d}  {100.0*v/max(tot,1):5.1f} %")

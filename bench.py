@@ -162,13 +162,20 @@ def algorithmic_flops(cnt, table, arr):
     n_l = max(1, len(kinds))
     f_pt = float(sum(1 for k in kinds if k)) / n_l                      # share of point lights (shadow rays are hits x lights)
     f = 0.0
-    # degree-3 surfaces: the strict build expands F(o + t d) term by term like the reference; the FMA build forms it from the surface's Taylor data at the ray origin
-    # (once per hit and wave, `cubic_points`) -- the device counts a point only where one is formed, so the choice of the per-test cost follows it
-    cub_unit = u["test_cubic_expand"] if cnt.get("cubic_points", 0) else u.get("test_cubic_dense", u["test_cubic_expand"])
-    f += ex["unitsq"] * u["test_unitsq"] + ex["quadric"] * u["test_quadric"] + ex["linear"] * u["test_linear"] + ex["cubic"] * cub_unit
+    # degree-3 surfaces: F(o + t d) from the surface's Taylor data at the ray origin (once per hit, `cubic_points`) through the guarded solver
+    # (rt_math.hpp, cubic_guarded: its own operation counts per branch; shadow rays take the shorter "decide" form of the trigonometric
+    # branch); the tests the guard hands back (`cubic_refused`) pay the reference's dense expansion and solver on top
+    f += ex["unitsq"] * u["test_unitsq"] + ex["quadric"] * u["test_quadric"] + ex["linear"] * u["test_linear"] + ex["cubic"] * u["test_cubic_expand"]
     f += cnt.get("cubic_points", 0) * u.get("cubic_point", 0)
     f += unit("solve_unitsq", so["unitsq"]) + unit("solve_quadric", so["quadric"]) + unit("solve_linear", so["linear"])
-    f += unit("cubic_cardano", cb["cardano"]) + unit("cubic_trig", cb["trig"]) + unit("cubic_quadratic", cb["quad"]) + unit("cubic_linear", cb["linear"])
+    n_cub_tests = max(1, ex["cubic"])
+    share_primary = min(1.0, cnt["primary_rays_formed"] * sum(1 for c in object_classes(arr) if c == "cubic") / n_cub_tests) if ex["cubic"] else 0.0
+    f += cb["cardano"] * u["cubic_guarded_cardano"] + cb["trig"] * (share_primary * u["cubic_guarded_trig"] + (1.0 - share_primary) * u["cubic_guarded_trig_decide"])
+    f += cb["quad"] * u["cubic_guarded_quadratic"] + cb["linear"] * u["cubic_guarded_linear"]
+    refused = cnt.get("cubic_refused", 0)
+    if refused:
+        mean_ref_solver = (cb["cardano"] * u["cubic_cardano"] + cb["trig"] * u["cubic_trig"] + cb["quad"] * u["cubic_quadratic"] + cb["linear"] * u["cubic_linear"]) / n_cub_tests
+        f += refused * (u["test_cubic_dense"] + mean_ref_solver)
     n_us = max(1, ex_objects_unitsq(arr))
     f += cu["tile"] * (u["cull_tile"] + u["tile_planes"] * 4.0 / max(4.0, float(n_us)))   # a classifying lane forms its tile's planes once for n_us / 4 spheres
     f += unit("cull_primary", cu["primary"]) + cu["shadow_directional"] * u["cull_shadow_directional"]

@@ -68,7 +68,7 @@ class Config(C.Structure):
 
 class CountersDetail(C.Structure):
     _fields_ = [("tests_executed", C.c_uint64 * 4), ("solves", C.c_uint64 * 3), ("cull_evals", C.c_uint64 * 5), ("cubic_branch", C.c_uint64 * 4),
-                ("shadow_rays_traced", C.c_uint64), ("hit_lights_shaded", C.c_uint64), ("primary_rays_formed", C.c_uint64), ("cubic_points", C.c_uint64)]
+                ("shadow_rays_traced", C.c_uint64), ("hit_lights_shaded", C.c_uint64), ("primary_rays_formed", C.c_uint64), ("cubic_points", C.c_uint64), ("cubic_refused", C.c_uint64)]
 
 
 class Counters(C.Structure):
@@ -424,6 +424,7 @@ class Renderer:
         d["shadow_rays_traced"], d["hit_lights_shaded"], d["primary_rays_formed"] = int(x.shadow_rays_traced), int(x.hit_lights_shaded), int(x.primary_rays_formed)
         d["cubic_branches"] = dict(zip(("cardano", "trig", "quad", "linear"), (int(v) for v in x.cubic_branch)))
         d["cubic_points"] = int(x.cubic_points)
+        d["cubic_refused"] = int(x.cubic_refused)
         return d
 
 

@@ -26,7 +26,7 @@ extern "C" hipError_t rt_launch_trace_fast(const FrameArgs *, const DevObject *,
 extern "C" hipError_t rt_launch_wavefront_strict(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, const double *, const double *, hipStream_t);
 extern "C" hipError_t rt_launch_wavefront_fast(const FrameArgs *, const DevObject *, const DevLight *, void *, unsigned long long *, int, const double *, const double *, hipStream_t);
 
-extern "C" size_t rt_wavefront_lds_bytes_strict(uint32_t, uint32_t, int, uint32_t, int);
+extern "C" size_t rt_wavefront_lds_bytes_strict(uint32_t, uint32_t, int, uint32_t, int, uint32_t);
 
 extern "C" hipError_t rt_launch_assemble_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, int, hipStream_t);
 extern "C" hipError_t rt_launch_pack_sparse_strict(const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
@@ -551,9 +551,9 @@ static int create_impl(rt_ctx **out, const rt_scene_desc *sd, const rt_config *c
         if (const char *e = std::getenv("MI355RT_LEAN")) ctx->lean_force = (e[0] == 'a') ? 1 : ((e[0] == 'n') ? -1 : 0);
     }
 
-    if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u, 0) > 160u * 1024u) {
+    if (!(cfg.flags & RT_FLAG_SIMPLE) && rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u, 0, fa.n_cub) > 160u * 1024u) {
         return fail(RT_ERR_SCENE, "rt_create: scene needs %zu bytes of LDS per workgroup (limit 160 KiB)",
-                    rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u, 0));
+                    rt_wavefront_lds_bytes_strict(fa.stage_bytes, sd->n_lights, (int) fa.has_mirror, fa.cull ? fa.n_us : 0u, 0, fa.n_cub));
     }
     int rc = RT_OK;
     auto hip_ok = [&](hipError_t err, const char *what) {
@@ -653,8 +653,12 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
 
     for (size_t j = 0; j * RT_NCOEF < ctx->cub_coefs.size(); j++) { // degree-3 objects: F, grad F, half Hessian at the frame's ray origin (rt_math.hpp, cubic_at)
         const rtm::CubicAt a = rtm::cubic_at(ctx->cub_coefs.data() + j * RT_NCOEF, rtm::D3{fa.origin[0], fa.origin[1], fa.origin[2]});
-        const double v[10] = {a.f, a.gx, a.gy, a.gz, a.hxx, a.hyy, a.hzz, a.hxy, a.hxz, a.hyz};
-        std::memcpy(fa.cub_at[j], v, sizeof(v));
+        const rtm::CubicAbs ab = rtm::cubic_abs(ctx->cub_coefs.data() + j * RT_NCOEF); // the bounds cubic_guarded works with (same functions as on the device)
+        const rtm::CubicMag mg = rtm::cubic_mag_origin(ab, rtm::D3{fa.origin[0], fa.origin[1], fa.origin[2]});
+        const double v[RT_CUB_REC] = {a.f, a.gx, a.gy, a.gz, a.hxx, a.hyy, a.hzz, a.hxy, a.hxz, a.hyz, mg.m3, mg.m2, mg.m1, mg.m0};
+        const double va[4] = {ab.a3, ab.a2, ab.a1, ab.a0};
+        std::memcpy(fa.cub_rec[j], v, sizeof(v));
+        std::memcpy(fa.cub_abs[j], va, sizeof(va));
     }
     { // tile pyramids of the early-out test (FrameArgs::tile_nt): inverse transpose of the camera's 3x3 part
         const double a = cam[0], b = cam[4], c = cam[8], d = cam[1], e = cam[5], f = cam[9], g = cam[2], h = cam[6], i = cam[10];
@@ -907,7 +911,7 @@ extern "C" int rt_get_counters_detail(rt_ctx *ctx, rt_counters_detail *out)
     if (!ctx || !out) return fail(RT_ERR_INVALID, "rt_get_counters_detail: null argument");
     if (!ctx->counted) return fail(RT_ERR_INVALID, "rt_get_counters_detail: the last render was not done with RT_FLAG_COUNT");
     if (ctx->cfg.flags & RT_FLAG_SIMPLE) return fail(RT_ERR_INVALID, "rt_get_counters_detail: the simple kernel does not split its counters");
-    unsigned long long h[20];
+    unsigned long long h[21];
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipDeviceSynchronize());
     RT_HIP(hipMemcpy(h, ctx->d_counters + 32, sizeof(h), hipMemcpyDeviceToHost));
@@ -919,6 +923,7 @@ extern "C" int rt_get_counters_detail(rt_ctx *ctx, rt_counters_detail *out)
     out->hit_lights_shaded = h[17];
     out->primary_rays_formed = h[18];
     out->cubic_points = h[19];
+    out->cubic_refused = h[20];
     return RT_OK;
 }
 

@@ -65,7 +65,7 @@ __device__ __forceinline__ int trace(const FrameArgs &fa, const DevObject *__res
     int best = -1;
     double best_t = INFINITY;
     for (uint32_t k = 0; k < fa.n_obj; k++) {
-        double t = intersect(gobj[k].c, gobj[k].cls, m);
+        double t = intersect(gobj[k].c, gobj[k].cls, m, MAX_T, false);
         cnt.test();
         if (t >= EPS && t < MAX_T && t < best_t) {
             best_t = t;
@@ -91,7 +91,7 @@ __device__ __forceinline__ int trace(const FrameArgs &fa, const DevObject *__res
         make_mono(sm, so, sd);
         bool in_shadow = false;
         for (uint32_t k = 0; k < fa.n_obj; k++) {
-            double t = intersect(gobj[k].c, gobj[k].cls, sm);
+            double t = intersect(gobj[k].c, gobj[k].cls, sm, max_t, true);
             cnt.test();
             if (t > EPS && t < max_t) {
                 in_shadow = true;

@@ -254,8 +254,7 @@ __device__ __forceinline__ double solve_cubic(double t3, double t2, double t1, d
 // Surfaces with degree-3 terms: dense expansion + full solver.  Kept out of line (one copy per kernel)
 // so that the common quadric path stays small in registers; it re-derives the degree <= 2 monomials from
 // (o, d), which is noise next to the ~300 flops and the cbrt/acos/cos of this path.
-__device__ __noinline__ double intersect_cubic(const double *c, double ox, double oy, double oz, double dx, double dy,
-                                               double dz)
+__device__ __forceinline__ double intersect_cubic_inl(const double *c, double ox, double oy, double oz, double dx, double dy, double dz)
 {
     Mono m;
     make_mono(m, D3{ox, oy, oz}, D3{dx, dy, dz});
@@ -263,6 +262,10 @@ __device__ __noinline__ double intersect_cubic(const double *c, double ox, doubl
     cubic_poly(c, m, t3, t2, t1, t0);
     if (fabs(t3) > EPS) return solve_cubic(t3, t2, t1, t0);
     return solve_quadlin(t2, t1, t0);
+}
+__device__ __noinline__ double intersect_cubic(const double *c, double ox, double oy, double oz, double dx, double dy, double dz)
+{
+    return intersect_cubic_inl(c, ox, oy, oz, dx, dy, dz);
 }
 
 // The same value, inlined, also naming the solver branch that produced it (counting builds only):
@@ -365,10 +368,276 @@ __device__ __forceinline__ double intersect_cubic_at_branch(const double *c, con
     return solve_quadlin(t2, t1, t0);
 }
 
-// intersect_ray, include/surface_impl.h:21-155: parameter of the root the reference would return.
-__device__ __forceinline__ double intersect(const double *__restrict__ c, uint32_t cls, const Mono &m)
+// ---- degree-3 surfaces, strict build: the Taylor polynomial behind a GUARD ----
+// The reference's solver (solve_cubic above, include/surface_impl.h:106-136) is not a continuous function of t3 .. t0: the sign of its
+// discriminant picks Cardano's formula or the trigonometric one, the trigonometric roots are filtered with `>= EPS`, callers compare
+// the result with EPS and max_t -- and where |t3| is small against the other coefficients, or q^3 << r^2, the formulas as written lose
+// most of their digits, so even their rounding noise depends on the exact bits of the coefficients.  The Taylor coefficients equal the
+// dense expansion's up to rounding only (both evaluate the same polynomial in o and d; each is off by some 30 roundings of its largest
+// term), so using them blindly moves pixels across those discontinuities (scenes/cayley.yml from the origin: F(0) = 0, a double root at
+// t = 0 in EVERY primary ray, Cardano-or-trigonometric decided by the last bit).  cubic_guarded therefore carries a running bound of
+// how far its result can be from what the reference's expressions give on the dense coefficients -- the coefficients' own uncertainty
+// (CubicMag: E x the sum of the absolute values of a coefficient's terms) pushed through every step of the solver, plus the roundings of
+// the steps themselves -- and refuses (returns false: the caller takes the dense expansion and the reference's solver, as before)
+// whenever a decision (|t3| > EPS, the discriminant's sign, a root against EPS or max_t) is closer to its threshold than CUB_K times
+// that bound, or an accepted root is uncertain by more than CUB_TOL of its value.  What it returns otherwise is the reference's result up
+// to CUB_TOL -- three orders of magnitude inside the 1e-5 the north star allows degree-3 scenes -- computed with one division instead
+// of nine and one sincos instead of three cosines (it need not mimic the reference's operation order: that is the guard's job).
+struct CubicMag {
+    double m3, m2, m1, m0; // uncertainty of t3 .. t0: CUB_E x an upper bound of the sum of the coefficient's |terms|
+};
+struct CubicAbs {        // per object: CUB_E x the sums of |coefficients| by degree
+    double a3, a2, a1, a0;
+};
+constexpr double CUB_E = 0x1p-46;   // relative uncertainty of a coefficient against the sum of its |terms| (dense vs Taylor evaluation: some 30 roundings each)
+__host__ __device__ __forceinline__ CubicAbs cubic_abs(const double *__restrict__ c)
 {
-    if (cls & RT_CLS_CUBIC) return intersect_cubic(c, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z);
+    CubicAbs a;
+    a.a3 = 0.0;
+    for (int k = K_X3; k <= K_XYZ; k++) a.a3 += fabs(c[k]);
+    a.a2 = 0.0;
+    for (int k = K_X2; k <= K_YZ; k++) a.a2 += fabs(c[k]);
+    a.a1 = (fabs(c[K_X]) + fabs(c[K_Y])) + fabs(c[K_Z]);
+    a.a0 = fabs(c[K_C]);
+    a.a3 *= CUB_E; a.a2 *= CUB_E; a.a1 *= CUB_E; a.a0 *= CUB_E;
+    return a;
+}
+// the origin's part of the bounds (once per origin) ...
+__host__ __device__ __forceinline__ CubicMag cubic_mag_origin(const CubicAbs &a, const D3 &o)
+{
+    const double s = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z));
+    CubicMag m;
+    m.m3 = a.a3;
+    m.m2 = 3.0 * a.a3 * s + a.a2;
+    m.m1 = (3.0 * a.a3 * s + 2.0 * a.a2) * s + a.a1;
+    m.m0 = ((a.a3 * s + a.a2) * s + a.a1) * s + a.a0;
+    return m;
+}
+// ... and the direction's (dmax = the largest |component| of d)
+__host__ __device__ __forceinline__ CubicMag cubic_mag_dir(const CubicMag &m, double dmax)
+{
+    const double d2 = dmax * dmax;
+    return CubicMag{m.m3 * d2 * dmax, m.m2 * d2, m.m1 * dmax, m.m0};
+}
+
+constexpr double CUB_U = 0x1p-52;
+constexpr double CUB_K = 16.0;      // safety factor between a decision's distance from its threshold and the bound
+constexpr double CUB_TOL = 1e-8;    // accepted relative uncertainty of a root that is used
+
+#ifdef RT_CUB_LAB // (tests/tools/cubic_guard_lab.cpp: which check sent a test back to the dense path)
+static int g_cub_why = 0;
+#define CUB_REFUSE(n) (g_cub_why = (n), false)
+#else
+#define CUB_REFUSE(n) false
+#endif
+
+// Reciprocals.  cub_rcpa: a few good digits are enough (error bounds, Newton corrections) -- on the device the bare v_rcp_f64, one
+// instruction where a division is a dozen; taken to be good to 2^-12 and never trusted beyond that (the host stand-in is made that bad
+// on purpose when RT_CUB_LAB is set, so the CPU experiment covers it).  cub_rcp: full precision, two Newton steps on top.
+__host__ __device__ __forceinline__ double cub_rcpa(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(x);
+#elif defined(RT_CUB_LAB)
+    return (1.0 / x) * (1.0 + 0x1p-13);
+#else
+    return 1.0 / x;
+#endif
+}
+__host__ __device__ __forceinline__ double cub_rcp(double x)
+{
+    double y = cub_rcpa(x);
+    y = fma(y, fma(-x, y, 1.0), y);
+    y = fma(y, fma(-x, y, 1.0), y);
+    return y;
+}
+
+// Square roots of this function's own intermediate values: v_rsq_f64 and two coupled Newton steps (no scaling for denormal or huge
+// arguments -- an argument out there ends in inf / NaN, which every check below refuses).  cub_rsqa: a few good digits (error bounds).
+__host__ __device__ __forceinline__ double cub_rsqa(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsq(x);
+#elif defined(RT_CUB_LAB)
+    return (1.0 / sqrt(x)) * (1.0 + 0x1p-13);
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+__host__ __device__ __forceinline__ double cub_sqrt(double x)
+{
+    const double y = cub_rsqa(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    return fma(fma(-g, g, x), h, g); // (one more correction of g alone: the result is within an ulp or two)
+}
+
+// false: no verdict (take the reference's path).  true: `t` is what the reference's solver returns for this ray up to CUB_TOL, and
+// every comparison the callers make with it (t >= EPS, t > EPS, t < max_t) comes out as with the reference's value.
+// Error bounds: e_i = mg.m_i >= 64 u |t_i| by construction (CubicMag), so the roundings of the steps below and of the reference's own
+// evaluation -- a few u of each term -- are an order of magnitude inside the propagated bounds and live in CUB_K's slack.
+// decide: the caller only asks "EPS < t < max_t?" (a shadow ray): a root that is used need not be sharp, and `t` need not be the root the
+// reference selects as long as that question gets the reference's answer.
+__host__ __device__ __forceinline__ bool cubic_guarded(double t3, double t2, double t1, double t0, const CubicMag &mg, double max_t, bool decide, double &t)
+{
+    const double at3 = fabs(t3);
+    const double e3 = mg.m3;
+    double root, eroot;
+    if (at3 > EPS + (EPS + CUB_K * e3)) { // ---- solve_cubic, include/surface_impl.h:106-136 ----
+        const double inv = cub_rcp(t3), ainv = fabs(inv);
+        const double a2 = t2 * inv, a1 = t1 * inv, a0 = t0 * inv;
+        const double r3 = e3 * ainv + 4.0 * CUB_U; // relative uncertainty of 1 / t3
+        const double ea2 = fma(mg.m2, ainv, fabs(a2) * r3);
+        const double ea1 = fma(mg.m1, ainv, fabs(a1) * r3);
+        const double ea0 = fma(mg.m0, ainv, fabs(a0) * r3);
+        const double a2s = a2 * a2;
+        const double q = fma(3.0, a1, -a2s) * (1.0 / 9.0);
+        const double eq = fma(3.0, ea1, 2.0 * fabs(a2) * ea2) * (1.0 / 9.0);
+        const double r = fma(fma(9.0, a1, -2.0 * a2s), a2, -27.0 * a0) * (1.0 / 54.0);
+        const double er = fma(9.0, fma(fabs(a2), ea1, fabs(a1) * ea2), fma(6.0 * a2s, ea2, 27.0 * ea0)) * (1.0 / 54.0);
+        const double q2 = q * q, q3 = q2 * q, r2 = r * r;
+        const double delta = q3 + r2;
+        const double ed = fma(3.0 * q2, eq, 2.0 * fabs(r) * er);
+        if (!(fabs(delta) > CUB_K * ed)) return CUB_REFUSE(2); // Cardano or trigonometric: not for this function to say
+        const double third_a2 = a2 * (1.0 / 3.0);
+        if (delta > 0.0) {
+            // one real root: cbrt(r + s) + cbrt(r - s) - a2 / 3.  Here: the cube root of the term that does not cancel, the other one from
+            // their product (-q); what the reference's cancelling term can be off by is in the bound (eab over the small root's square)
+            const double s = cub_sqrt(delta);
+            const double es = ed * cub_rcpa(s); // (>= ed / (2 s))
+            const double eab = er + es;
+            const double ca = cbrt(r + copysign(s, r));
+            const double ra = cub_rcp(ca);
+            const double cb = -q * ra;
+            const double rb = cub_rcpa(cb); // (cb = 0: infinite -- refused below)
+            root = (ca + cb) - third_a2;
+            eroot = fma(eab * (1.0 / 3.0), fma(ra, ra, rb * rb), fma(eq, fabs(ra), ea2 * (1.0 / 3.0)));
+        } else {
+            // three real roots 2 m cos(theta + 2 k pi / 3) - a2 / 3, cos(3 theta) = r / m^3.  No acos / cos: c = cos(theta) is the root of
+            // 4 c^3 - 3 c = arg in [1/2, 1], four Newton steps from 1/2 + sqrt((1 + arg) / 8) (good to 0.016: 8e-4, 2e-6, 3e-10, 3e-14 with a
+            // reciprocal that is only good to 2^-13); the size of the last correction -- the error before it -- is taken as the error after it.  sin(theta) >= 0 from c.
+            const double m2 = -q; // > 0: delta < 0 means q^3 < -r^2 <= 0
+            const double m = cub_sqrt(m2);
+            const double rm = cub_rcp(m), rm3 = rm * rm * rm;
+            const double em = 0.5 * eq * rm;
+            const double arg = r * rm3;
+            const double earg = fma(3.0 * fabs(arg) * m2, em, er) * rm3;
+            const double w2 = -delta * (rm3 * rm3); // 1 - arg^2, without the cancellation
+            double c = 0.5 + (double) sqrtf((float) fma(0.125, arg, 0.125));
+            double dc = 0.0;
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const double c2 = c * c;
+                dc = fma(fma(4.0, c2, -3.0), c, -arg) * cub_rcpa(fma(12.0, c2, -3.0));
+                c -= dc;
+            }
+            const double eth = earg * (1.0 / 3.0) * cub_rsqa(w2); // of theta
+            const double ec = fabs(dc) + 4.0 * CUB_U;            // of c, on top of theta's
+            const double two_m = 2.0 * m;
+            const double x0 = fma(two_m, c, -third_a2); // the largest root
+            const double e0 = fma(two_m, eth + ec, fma(2.0, em, ea2 * (1.0 / 3.0))); // (|d cos| <= |d theta|)
+            bool done = false;
+            if (decide) {
+                // the reference returns the smallest root >= EPS, or x0 when only x0 or none is: with x0 < EPS that is x0 itself (no), with
+                // EPS < x0 < max_t whatever it returns lies in [EPS, x0] (yes; `t > EPS` is `t >= EPS` away from the band) -- the other two
+                // roots matter only when x0 is beyond max_t
+                const double band0 = CUB_K * e0;
+                if (!(fabs(x0 - EPS) > band0 && fabs(x0 - max_t) > band0)) return CUB_REFUSE(7);
+                done = x0 < max_t;
+                root = x0;
+                eroot = e0;
+            }
+            if (!done) {
+                const double sn = cub_sqrt(fmax(fma(-c, c, 1.0), 0.0));
+                const double hs = 0.86602540378443864676 * sn; // cos(theta +- 2 pi / 3) = -cos(theta) / 2 -+ sqrt(3) / 2 sin(theta)
+                const double x1 = fma(two_m, fma(-0.5, c, -hs), -third_a2); // the smallest root
+                const double x2 = fma(two_m, fma(-0.5, c, hs), -third_a2);  // the middle one
+                eroot = fma(two_m, eth + ec * (1.0 + c * cub_rcpa(fmax(sn, 0x1p-500))), fma(2.0, em, ea2 * (1.0 / 3.0)));
+                const double band = CUB_K * eroot;
+                if (!(fabs(x1 - EPS) > band && fabs(x2 - EPS) > band)) return CUB_REFUSE(3); // the reference filters these two with `>= EPS`
+                root = x0;
+                if (x1 >= EPS && x1 < root) root = x1;
+                if (x2 >= EPS && x2 < root) root = x2;
+            }
+        }
+    } else if (at3 + CUB_K * e3 < EPS) { // ---- solve_quadlin, include/surface_impl.h:138-154 ----
+        const double at2 = fabs(t2), at1 = fabs(t1);
+        const double e2 = mg.m2, e1 = mg.m1, e0 = mg.m0;
+        if (at2 > EPS + (EPS + CUB_K * e2)) {
+            const double t20 = t2 * t0;
+            const double delta = fma(t1, t1, -4.0 * t20);
+            const double ed = fma(2.0 * at1, e1, 4.0 * fma(at2, e0, fabs(t0) * e2));
+            if (!(fabs(delta) > CUB_K * ed)) return CUB_REFUSE(4);
+            if (delta < 0.0) {
+                t = -1.0;
+                return true;
+            }
+            const double s = cub_sqrt(delta), es = ed * cub_rcpa(s);
+            const double h = 0.5 * cub_rcp(t2), ah = fabs(h);
+            const double rel2 = 2.0 * e2 * ah + 4.0 * CUB_U;
+            const double en = e1 + es; // of the numerators -t1 -+ s
+            const double xa = (-t1 - s) * h;
+            const double exa = fma(en, ah, fabs(xa) * rel2);
+            if (!(fabs(xa - EPS) > CUB_K * exa)) return CUB_REFUSE(5); // `if (x >= EPS) return x;`
+            if (xa >= EPS) {
+                root = xa;
+                eroot = exa;
+            } else {
+                root = (-t1 + s) * h;
+                eroot = fma(en, ah, fabs(root) * rel2);
+            }
+        } else if (at2 + CUB_K * e2 < EPS) {
+            if (at1 > EPS + (EPS + CUB_K * e1)) {
+                const double r1 = cub_rcp(t1);
+                root = -t0 * r1;
+                eroot = fma(fabs(root), e1, e0) * fabs(r1) + (4.0 * CUB_U) * fabs(root);
+            } else if (at1 + CUB_K * e1 < EPS) {
+                t = -1.0;
+                return true;
+            } else {
+                return CUB_REFUSE(6);
+            }
+        } else {
+            return CUB_REFUSE(6);
+        }
+    } else {
+        return CUB_REFUSE(1); // |t3| too close to EPS (NaN lands here too)
+    }
+    t = root;
+    const double band = CUB_K * eroot;
+    if (!(fabs(root - EPS) > band && fabs(root - max_t) > band)) return CUB_REFUSE(7); // the callers' comparisons
+    if (!decide && !(root < EPS || root >= max_t || eroot <= CUB_TOL * root)) return CUB_REFUSE(8); // a root that is used must be sharp
+    return true;
+}
+
+// A degree-3 object against the ray (o, d), as both kernels do it: the Taylor coefficients from the surface's data at o (`ca`, and `mo` =
+// cubic_mag_origin there) through cubic_guarded; where the guard refuses, the dense expansion and the reference's solver.  max_t: what the
+// caller compares the result with (MAX_T for a nearest-hit search).  `refused` reports which way it went (work counters).
+template <bool DENSE_INLINE = false> // (DENSE_INLINE: the caller is itself an out-of-line function -- a call from there would need a stack frame)
+__device__ __forceinline__ double intersect_cubic_taylor(const double *__restrict__ c, const CubicAt &ca, const CubicMag &mo, const D3 &o, const D3 &d, double max_t,
+                                                         bool decide, bool &refused)
+{
+    double t3, t2, t1, t0, t;
+    cubic_coefs(c, ca, d, t3, t2, t1, t0);
+    const CubicMag mg = cubic_mag_dir(mo, fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z)));
+    refused = !cubic_guarded(t3, t2, t1, t0, mg, max_t, decide, t);
+    if (refused) t = DENSE_INLINE ? intersect_cubic_inl(c, o.x, o.y, o.z, d.x, d.y, d.z) : intersect_cubic(c, o.x, o.y, o.z, d.x, d.y, d.z);
+    return t;
+}
+
+// intersect_ray, include/surface_impl.h:21-155: parameter of the root the reference would return (degree <= 2: exactly; degree 3: see
+// cubic_guarded).  max_t, decide as above.
+__device__ __forceinline__ double intersect(const double *__restrict__ c, uint32_t cls, const Mono &m, double max_t, bool decide)
+{
+    if (cls & RT_CLS_CUBIC) {
+        bool refused;
+        return intersect_cubic_taylor(c, cubic_at(c, m.o), cubic_mag_origin(cubic_abs(c), m.o), m.o, m.d, max_t, decide, refused);
+    }
     double t2, t1, t0;
     quadric_poly(c, cls, m, t2, t1, t0);
     return solve_quadlin(t2, t1, t0);

@@ -163,10 +163,10 @@ constexpr int wf_occupancy()
 //             39-43 culling: tile pyramid, primary cone, shadow phase directional / point light, records formed
 //             44-47 cubic tests by solver branch   48 shadow rays traced (of counters[1] considered)   49 hits shaded per light
 //             50 primary rays formed (pixels of the tiles that are traced; counters[0] counts every pixel, as the reference does)
-//             51 Taylor data of a degree-3 surface formed at a ray origin (lanes)
+//             51 Taylor data of a degree-3 surface formed at a ray origin (lanes)   52 degree-3 tests the guard handed to the dense path
 enum { K_US = 0, K_GQ = 1, K_LIN = 2, K_CUB = 3 };
 enum { C_TILE = 0, C_PRIMARY = 1, C_SHADOW_DIR = 2, C_SHADOW_SPH = 3, C_RECORDS = 4 };
-constexpr int N_CNT_W = 20;
+constexpr int N_CNT_W = 21;
 template <bool COUNT>
 struct Cnt {
     __device__ __forceinline__ void add(int, unsigned long long = 1) {}
@@ -178,12 +178,13 @@ struct Cnt {
     __device__ __forceinline__ void shaded() {}
     __device__ __forceinline__ void primary_traced() {}
     __device__ __forceinline__ void cubic_point() {}
+    __device__ __forceinline__ void cubic_refused(bool) {}
     __device__ __forceinline__ void flush(unsigned long long *) {}
 };
 template <>
 struct Cnt<true> {
     unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t w[N_CNT_W] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // per thread and frame: 32 bits are plenty
+    uint32_t w[N_CNT_W] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // per thread and frame: 32 bits are plenty
     __device__ __forceinline__ void add(int i, unsigned long long n = 1) { v[i] += n; }
     __device__ __forceinline__ void exec(int cls, unsigned long long n) { v[6] += n; w[cls] += (uint32_t) n; }
     __device__ __forceinline__ void solve(int cls) { v[5] += 1; w[4 + cls] += 1; }
@@ -198,11 +199,14 @@ struct Cnt<true> {
     __device__ __forceinline__ void shaded() { w[17] += 1; }
     __device__ __forceinline__ void primary_traced() { w[18] += 1; }
     __device__ __forceinline__ void cubic_point() { w[19] += 1; } // Taylor data of a degree-3 surface formed at a ray origin (rt_math.hpp, cubic_at)
+    __device__ __forceinline__ void cubic_refused(bool r) { w[20] += r; } // degree-3 tests that cubic_guarded handed to the dense expansion + the reference's solver
     __device__ __forceinline__ void flush(unsigned long long *g)
     {
+#pragma unroll
         for (int i = 0; i < 8; i++)
             if (v[i]) atomicAdd(&g[i], v[i]);
-        for (int i = 0; i < N_CNT_W; i++)
+#pragma unroll
+        for (int i = 0; i < N_CNT_W; i++) // (fully unrolled: an indexed access would move the counters to scratch memory)
             if (w[i]) atomicAdd(&g[32 + i], (unsigned long long) w[i]);
     }
 };
@@ -215,6 +219,8 @@ struct SceneLds {
     const uint32_t *cub;
     const MatEntry *mat;
     const DevLight *light;
+    uint32_t cubrec, cubtmp, cubprim; // degree-3 scenes: LDS byte addresses of the record regions (LdsLayout)
+    double *cubtmp_p;                 // the working records again, as a pointer for the stores
 };
 
 // Workgroup barrier for LDS-only communication: release/acquire at workgroup scope on the LDS address space only,
@@ -225,6 +231,35 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// ---- degree-3 objects: one test, out of line ----
+// The surface's Taylor data at the ray origin and the error bounds that go with it (rt_math.hpp: CubicAt, CubicMag) wait in LDS as a
+// record of RT_CUB_REC doubles: rec + i * stride (bytes) is double i -- stride 8 for the packed records of the frame's origin, 8 * WG for
+// the per-hit / per-lane ones.  Out of line (one copy per kernel, like the dense path it falls back to) and with few arguments: inlined
+// at both call sites the guarded solver costs the instantiation a wave per SIMD.
+typedef const __attribute__((address_space(3))) double *LdsD;
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) void *) p; }
+__device__ __forceinline__ void cubic_rec_store(double *rec, uint32_t stride_d, const CubicAt &a, const CubicMag &m)
+{
+    rec[0] = a.f; rec[stride_d] = a.gx; rec[2 * stride_d] = a.gy; rec[3 * stride_d] = a.gz;
+    rec[4 * stride_d] = a.hxx; rec[5 * stride_d] = a.hyy; rec[6 * stride_d] = a.hzz; rec[7 * stride_d] = a.hxy; rec[8 * stride_d] = a.hxz; rec[9 * stride_d] = a.hyz;
+    rec[10 * stride_d] = m.m3; rec[11 * stride_d] = m.m2; rec[12 * stride_d] = m.m1; rec[13 * stride_d] = m.m0;
+}
+template <bool DENSE_INLINE>
+__device__ __forceinline__ double cubic_test_body(const double *c, uint32_t rec, uint32_t stride, double ox, double oy, double oz, double dx, double dy, double dz, double max_t, bool decide,
+                                                  bool &refused)
+{
+#define RT_REC(i) (*(LdsD) (uintptr_t) (rec + (i) * stride))
+    const CubicAt ca{RT_REC(0), RT_REC(1), RT_REC(2), RT_REC(3), RT_REC(4), RT_REC(5), RT_REC(6), RT_REC(7), RT_REC(8), RT_REC(9)};
+    const CubicMag mo{RT_REC(10), RT_REC(11), RT_REC(12), RT_REC(13)};
+#undef RT_REC
+    return intersect_cubic_taylor<DENSE_INLINE>(c, ca, mo, D3{ox, oy, oz}, D3{dx, dy, dz}, max_t, decide, refused);
+}
+__device__ __noinline__ double cubic_test(const double *c, uint32_t rec, uint32_t stride, double ox, double oy, double oz, double dx, double dy, double dz, double max_t, bool decide)
+{
+    bool refused;
+    return cubic_test_body<true>(c, rec, stride, ox, oy, oz, dx, dy, dz, max_t, decide, refused);
 }
 
 // Cross-lane helpers.  Reductions run on DPP row operations (VALU latency) instead of ds_bpermute round trips
@@ -610,36 +645,32 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
         for (uint32_t j = 0; j < fa.n_cub; j++) {
             const uint32_t k = __builtin_amdgcn_readfirstlane(S.cub[j]);
             if (live) {
-                // F(o + t d) from the surface's Taylor data at the ray origin (rt_math.hpp, CubicAt): for primary rays the origin is the
-                // frame's, and rt_render has evaluated the data of the first RT_CUB_AT_MAX degree-3 objects there (uniform: scalar loads)
-                double t;
-#if RT_FAST
-                // (FMA build only: the strict build keeps the reference's expansion, term by term -- the re-association flips 0.1 % of the
-                // pixels of scenes/cayley.yml across a solver discontinuity, more than two CPU builds of the reference differ by, and buys 2 %)
-                CubicAt ca;
+                // F(o + t d) from the surface's Taylor data at the ray origin (rt_math.hpp: CubicAt, cubic_guarded), which waits in LDS: for
+                // primary rays the origin is the frame's, and rt_render has evaluated the data of the first RT_CUB_AT_MAX degree-3 objects
+                // there (S.cubprim, copied at staging); other rays form it in their lane's working record.  Where the guard refuses, the
+                // reference's dense expansion and solver.
+                uint32_t rec, stride;
                 if (PRIMARY && j < RT_CUB_AT_MAX) {
-                    const double *q = fa.cub_at[j];
-                    ca = CubicAt{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9]};
+                    rec = S.cubprim + j * (RT_CUB_REC * 8u);
+                    stride = 8u;
                 } else {
-                    ca = cubic_at(gobj[k].c, m.o);
+                    rec = S.cubtmp + (threadIdx.x << 3);
+                    stride = WG * 8u;
+                    cubic_rec_store(S.cubtmp_p + threadIdx.x, WG, cubic_at(gobj[k].c, m.o),
+                                    cubic_mag_origin(j < RT_CUB_AT_MAX ? CubicAbs{fa.cub_abs[j][0], fa.cub_abs[j][1], fa.cub_abs[j][2], fa.cub_abs[j][3]} : cubic_abs(gobj[k].c), m.o));
                     cnt.cubic_point();
                 }
-                if (COUNT) { // counting builds also report which solver branch ran (flop accounting of bench.py)
-                    int br;
-                    t = intersect_cubic_at_branch(gobj[k].c, ca, m.d, br);
+                double t;
+                if (COUNT) { // counting builds also report which solver branch ran (flop accounting of bench.py): the guard answers only where the
+                    int br;  // branch is beyond doubt, so the dense classification names it either way
+                    bool refused;
+                    t = cubic_test_body<false>(gobj[k].c, rec, stride, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, MAX_T, false, refused);
+                    (void) intersect_cubic_branch(gobj[k].c, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, br);
                     cnt.cubic(br);
+                    cnt.cubic_refused(refused);
                 } else {
-                    t = intersect_cubic_at(gobj[k].c, ca, m.d);
+                    t = cubic_test(gobj[k].c, rec, stride, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, MAX_T, false);
                 }
-#else
-                if (COUNT) { // counting builds also report which solver branch ran (flop accounting of bench.py)
-                    int br;
-                    t = intersect_cubic_branch(gobj[k].c, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, br);
-                    cnt.cubic(br);
-                } else {
-                    t = intersect_cubic(gobj[k].c, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z);
-                }
-#endif
                 accept(t, (int) k, best_t, best);
             }
         }
@@ -671,8 +702,8 @@ constexpr uint32_t CREC_MAX = 64; // culling records cover the first group of 64
 
 // LDS carve-up (dynamic shared memory), shared by kernel and launcher.
 struct LdsLayout {
-    uint32_t scene, light, hp, hn, hdir, park, hidx, hpix, color, shadow, ball, box, crec, n_crec, misc, total, shadow_words;
-    __host__ __device__ LdsLayout(uint32_t scene_bytes, uint32_t n_lights, bool has_mirror, uint32_t n_cull_spheres, bool lean = false)
+    uint32_t scene, light, hp, hn, hdir, park, hidx, hpix, color, shadow, ball, box, crec, n_crec, misc, cubrec, cubtmp, cubprim, total, shadow_words;
+    __host__ __device__ LdsLayout(uint32_t scene_bytes, uint32_t n_lights, bool has_mirror, uint32_t n_cull_spheres, bool lean = false, uint32_t n_cub = 0)
     {
         const uint32_t Q = lean ? 0u : WG; // the lean path keeps a wave's hits in registers: no queue, no shadow bits, no colour exchange
         n_crec = n_cull_spheres < CREC_MAX ? n_cull_spheres : CREC_MAX; // culling records per chunk (0: culling is off)
@@ -693,6 +724,12 @@ struct LdsLayout {
         box = off; off = align16(off + 4 * (uint32_t) sizeof(BoxH));
         crec = off; off = align16(off + 4 * n_crec * (uint32_t) sizeof(CullRec));
         misc = off; off = align16(off + 64);
+        // degree-3 scenes: RT_CUB_REC doubles per record (rt_math.hpp: CubicAt + the origin's error bounds) -- one per hit, at its shadow-ray origin
+        // (first degree-3 object; SoA, stride WG), one per lane as working space (rays that do not start at the frame's origin, further
+        // degree-3 objects: only scenes with mirrors or several such objects), and RT_CUB_AT_MAX packed ones at the frame's origin
+        cubrec = off; off = align16(off + (n_cub ? RT_CUB_REC * WG * 8u : 0u));
+        cubtmp = off; off = align16(off + ((n_cub > 1u || (n_cub && has_mirror)) ? RT_CUB_REC * WG * 8u : 0u));
+        cubprim = off; off = align16(off + (n_cub ? RT_CUB_REC * RT_CUB_AT_MAX * 8u : 0u));
         total = off;
     }
 };
@@ -708,7 +745,7 @@ constexpr int NO_BLOCKER = 0x7fffffff;
 template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool SPHERICAL, bool OWN = false, typename Light = DevLight> // SPHERICAL: the light's kind -- one copy of the loop per kind, each without the other's code
 __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLds &S, const DevObject *__restrict__ gobj,
                                               const Mono &sm, double max_t, bool valid, bool prod, const Ball *ballp, const BoxH *boxp, const CullRec *crec, const Light &lt,
-                                              uint32_t lane, Cnt<COUNT> &cnt, uint32_t own = 0, bool own_skip = false, unsigned long long own_excl = 0ull, const CubicAt *ca0 = nullptr)
+                                              uint32_t lane, Cnt<COUNT> &cnt, uint32_t own = 0, bool own_skip = false, unsigned long long own_excl = 0ull, uint32_t cub_rec0 = 0u)
 {
     // valid: lanes whose ray is tested.  prod: lanes the product build tests (== valid there); a counting build tests more lanes --
     // all that have a hit -- and counts executed work for the `prod` ones only (wave-level work: if any lane is one).
@@ -810,34 +847,26 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
         for (uint32_t j = 0; j < fa.n_cub; j++) {
             const uint32_t k = __builtin_amdgcn_readfirstlane(S.cub[j]);
             if (valid && (int) k < blocker && (COUNT || blocker == NO_BLOCKER)) {
-                // the surface's Taylor data at the shadow-ray origin: the same for every light, so the caller forms it once per chunk for
-                // the scene's first degree-3 object (ca0); further ones are evaluated here
-                double t;
-#if RT_FAST
-                CubicAt ca;
-                if (j == 0 && ca0) {
-                    ca = *ca0;
-                } else {
-                    ca = cubic_at(gobj[k].c, sm.o);
+                // the surface's Taylor data at the shadow-ray origin is the same for every light: phase A' has put the first degree-3 object's
+                // into the hit's record (cub_rec0: its LDS address); further objects form theirs in the lane's working record
+                uint32_t rec = cub_rec0;
+                if (j != 0) {
+                    rec = S.cubtmp + (threadIdx.x << 3);
+                    cubic_rec_store(S.cubtmp_p + threadIdx.x, WG, cubic_at(gobj[k].c, sm.o),
+                                    cubic_mag_origin(j < RT_CUB_AT_MAX ? CubicAbs{fa.cub_abs[j][0], fa.cub_abs[j][1], fa.cub_abs[j][2], fa.cub_abs[j][3]} : cubic_abs(gobj[k].c), sm.o));
                     if (prod) cnt.cubic_point();
                 }
+                double t;
                 if (COUNT) {
                     int br;
-                    t = intersect_cubic_at_branch(gobj[k].c, ca, sm.d, br);
+                    bool refused;
+                    t = cubic_test_body<false>(gobj[k].c, rec, WG * 8u, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z, max_t, true, refused);
+                    (void) intersect_cubic_branch(gobj[k].c, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z, br);
                     cnt.cubic(br, prod);
+                    if (prod) cnt.cubic_refused(refused);
                 } else {
-                    t = intersect_cubic_at(gobj[k].c, ca, sm.d);
+                    t = cubic_test(gobj[k].c, rec, WG * 8u, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z, max_t, true);
                 }
-#else
-                (void) ca0;
-                if (COUNT) {
-                    int br;
-                    t = intersect_cubic_branch(gobj[k].c, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z, br);
-                    cnt.cubic(br, prod);
-                } else {
-                    t = intersect_cubic(gobj[k].c, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z);
-                }
-#endif
                 if (t > EPS && t < max_t) blocker = (int) k;
             }
         }
@@ -1215,7 +1244,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool NEED_CROSS = HAS_GQ || HAS_CUBIC;
     static_assert(!LEAN || (!HAS_GQ && !HAS_CUBIC && !HAS_MIRROR), "the lean path renders unit spheres only");
-    const LdsLayout L(fa.stage_bytes, fa.n_lights, HAS_MIRROR, fa.cull ? fa.n_us : 0u, LEAN);
+    const LdsLayout L(fa.stage_bytes, fa.n_lights, HAS_MIRROR, fa.cull ? fa.n_us : 0u, LEAN, HAS_CUBIC ? fa.n_cub : 0u);
     const DevObject *gobj = reinterpret_cast<const DevObject *>(gscene); // full object records: global memory only
     SceneLds S; // class tables + materials staged in LDS (only tiles with hits ever stage them); LDS offset = blob offset - off_us
     S.us = reinterpret_cast<const UsEntry *>(smem + L.scene);
@@ -1224,6 +1253,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     S.cub = reinterpret_cast<const uint32_t *>(smem + L.scene + (fa.off_cub - fa.off_us));
     S.mat = reinterpret_cast<const MatEntry *>(smem + L.scene + (fa.off_mat - fa.off_us));
     S.light = reinterpret_cast<const DevLight *>(smem + L.light);
+    S.cubrec = lds_addr(smem + L.cubrec); S.cubtmp = lds_addr(smem + L.cubtmp); S.cubprim = lds_addr(smem + L.cubprim);
+    S.cubtmp_p = reinterpret_cast<double *>(smem + L.cubtmp);
     SceneLds G; // the same tables where they live in global memory (round 0 runs straight from there)
     G.mat = reinterpret_cast<const MatEntry *>(gscene + fa.off_mat);
     G.us = reinterpret_cast<const UsEntry *>(gscene + fa.off_us);
@@ -1231,6 +1262,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
     G.lin = reinterpret_cast<const LinEntry *>(gscene + fa.off_lin);
     G.cub = reinterpret_cast<const uint32_t *>(gscene + fa.off_cub);
     G.light = glight;
+    G.cubrec = S.cubrec; G.cubtmp = S.cubtmp; G.cubprim = S.cubprim; G.cubtmp_p = S.cubtmp_p; // (LDS either way)
     double *hp = reinterpret_cast<double *>(smem + L.hp);   // [3][WG] hit points (SoA: lane-consecutive, conflict-free)
     double *hn = reinterpret_cast<double *>(smem + L.hn);   // [3][WG] hit normals
     double *hdir = reinterpret_cast<double *>(smem + L.hdir); // [3][WG] ray direction of the pixel, parked across phases B / C (mirrors only)
@@ -1539,6 +1571,15 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             }
         } else {
         bool first = true;
+        if (HAS_CUBIC && fa.n_cub != 0u) {
+            // degree-3 objects: the records of the frame's ray origin (FrameArgs::cub_rec) into LDS, where cubic_test reads them.  Every wave
+            // writes all of them -- the same values to the same words -- and reads them back only after its own stores (LDS operations of a
+            // wave complete in order): no workgroup barrier in front of round 0.
+            double *prim = reinterpret_cast<double *>(smem + L.cubprim);
+            if (lane < RT_CUB_REC * RT_CUB_AT_MAX) prim[lane] = (&fa.cub_rec[0][0])[lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        }
         if (fa.sparse && tid == 0) s_sparse[0] = 0xFFFFFFFFu; // visible after the first barrier of round 0
         if (!(hot_flags & 2u) && tid == 0) s_half[0] = 0u;    // (with the lists on, wave 0 wrote it with the decode)
         if (tid == 0) s_zero[0] = 0u;
@@ -1641,6 +1682,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             if (wave < n_chunks) { // wave-uniform
                 const bool v = tid < n_hits;
                 const double px = hp[v ? tid : wave * 64u], py = hp[WG + (v ? tid : wave * 64u)], pz = hp[2 * WG + (v ? tid : wave * 64u)];
+                if (fa.n_us != 0u) { // (launch-uniform: box, ball and records only serve the culling of spheres)
                 // Bounding box of the chunk's hit points, reduced in FP32 with outward rounding (a box that is one float ulp larger
                 // costs nothing -- it only feeds the conservative culling -- and a 32-bit DPP min / max step is one instruction
                 // where the FP64 one is five); centre and radius of its ball in FP64.
@@ -1661,6 +1703,19 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 // the light-independent half of the shadow-phase culling, lane = sphere (first group of 64)
                 if (lane < L.n_crec) screc[wave * L.n_crec + lane] = cull_record(S.us[lane], b);
                 if (lane == 0) cnt.cull(C_RECORDS, L.n_crec);
+                }
+                if (HAS_CUBIC && fa.n_cub != 0u) {
+                    // degree-3 scenes: the first such object's Taylor data (and error bounds) at this hit's shadow-ray origin -- the same for every
+                    // light -- into the hit's record; the origin is formed exactly as phase B forms it
+                    const uint32_t hs = v ? tid : wave * 64u;
+                    const D3 so{px + SHADOW_BIAS * hn[hs], py + SHADOW_BIAS * hn[WG + hs], pz + SHADOW_BIAS * hn[2 * WG + hs]};
+                    const double *c0 = gobj[__builtin_amdgcn_readfirstlane(S.cub[0])].c;
+                    if (v) {
+                        cubic_rec_store(reinterpret_cast<double *>(smem + L.cubrec) + tid, WG, cubic_at(c0, so),
+                                        cubic_mag_origin(CubicAbs{fa.cub_abs[0][0], fa.cub_abs[0][1], fa.cub_abs[0][2], fa.cub_abs[0][3]}, so));
+                        cnt.cubic_point();
+                    }
+                }
             }
             lds_barrier();
             RT_STAMP(5);
@@ -1687,13 +1742,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 const uint32_t own = (hinfo_b >> 8) & 0x7FFFFFu;
                 const bool own_ok = OWNG && valid && (hinfo_b >> 31) != 0u && fa.n_us == fa.n_obj;
                 const CullRec *my_crec = reinterpret_cast<const CullRec *>(smem + (L.crec + c * L.n_crec * (uint32_t) sizeof(CullRec)));
-                // degree-3 scenes, FMA build: the first such object's Taylor data at this hit's shadow-ray origin, once for all the lights this wave takes
-                CubicAt ca0{};
-                const bool have_ca0 = RT_FAST && HAS_CUBIC && fa.n_cub != 0u && ((wave + 4u - (c & 3u)) & 3u) < fa.n_lights; // (FMA build only: see nearest())
-                if (have_ca0) {
-                    ca0 = cubic_at(gobj[__builtin_amdgcn_readfirstlane(S.cub[0])].c, sm.o);
-                    if (valid) cnt.cubic_point();
-                }
+                const uint32_t cub_rec0 = HAS_CUBIC ? S.cubrec + (hs << 3) : 0u; // degree-3 scenes: this hit's record (phase A')
                 for (uint32_t l = (wave + 4u - (c & 3u)) & 3u; l < fa.n_lights; l += 4) {
                     // the light through the constant address space (LightK, rt_scene_dev.h): scalar loads, its fields in SGPRs; one body per
                     // light kind, nothing merged between them
@@ -1721,7 +1770,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                             mono_set_od<NEED_CROSS>(sd);
                             if (wanted) cnt.traced();
                             const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, false, OWNG>(fa, S, gobj, sd, 1e6, COUNT ? valid : wanted, wanted, sball + c, sbox + c, my_crec, lk, lane, cnt,
-                                                                                                      own, own_ok && bfe && quad_l && wanted, 0ull, have_ca0 ? &ca0 : nullptr);
+                                                                                                      own, own_ok && bfe && quad_l && wanted, 0ull, cub_rec0);
                             // the reference stops at the first blocker in index order (src/update-cpu.cpp:66-71)
                             if (valid) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
                             skip |= __ballot(valid && blocker != NO_BLOCKER);
@@ -1745,7 +1794,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                             mono_set_od<NEED_CROSS>(sd);
                             if (wanted) cnt.traced();
                             const int blocker = shadow_blocker<COUNT, HAS_GQ, HAS_CUBIC, true, OWNG>(fa, S, gobj, sd, 1.0, COUNT ? valid : wanted, wanted, sball + c, sbox + c, my_crec, lk, lane, cnt,
-                                                                                                     0u, false, 0ull, have_ca0 ? &ca0 : nullptr);
+                                                                                                     0u, false, 0ull, cub_rec0);
                             if (valid) cnt.add(3, blocker != NO_BLOCKER ? (unsigned long long) blocker + 1ull : (unsigned long long) fa.n_obj);
                             skip = __ballot(valid && blocker != NO_BLOCKER);
                         } else if (COUNT && valid) {
@@ -1915,9 +1964,9 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
 
 } // namespace RT_SYM(rtw)
 
-extern "C" size_t RT_SYM(rt_wavefront_lds_bytes)(uint32_t stage_bytes, uint32_t n_lights, int has_mirror, uint32_t n_cull_spheres, int lean)
+extern "C" size_t RT_SYM(rt_wavefront_lds_bytes)(uint32_t stage_bytes, uint32_t n_lights, int has_mirror, uint32_t n_cull_spheres, int lean, uint32_t n_cub)
 {
-    return RT_SYM(rtw)::LdsLayout(stage_bytes, n_lights, has_mirror != 0, n_cull_spheres, lean != 0).total;
+    return RT_SYM(rtw)::LdsLayout(stage_bytes, n_lights, has_mirror != 0, n_cull_spheres, lean != 0, n_cub).total;
 }
 
 // One workgroup per 16x16 tile; the dispatcher hands tiles to CUs as they free up, which is the dynamic load
@@ -1941,7 +1990,7 @@ extern "C" hipError_t RT_SYM(rt_launch_wavefront)(const FrameArgs *fa, const Dev
     // the lean path (rt_render decides: unit spheres only, all cullable, no mirrors, dense output): instantiations 16 / 17
     const bool lean = fa->lean && (sel & 7) == 0 && fa->all_cullable && fa->n_us == fa->n_obj && !fa->sparse;
     if (lean) sel = count ? 17 : 16;
-    const size_t lds = LdsLayout(fa->stage_bytes, fa->n_lights, fa->has_mirror != 0, fa->cull ? fa->n_us : 0u, lean).total;
+    const size_t lds = LdsLayout(fa->stage_bytes, fa->n_lights, fa->has_mirror != 0, fa->cull ? fa->n_us : 0u, lean, fa->n_cub).total;
     const bool ordering = fa->order_state && fa->ord_on;
     const unsigned char *hot_us = gs + fa->off_us;
     const uint32_t *hot_ord_rd = ordering ? fa->order_state + (size_t) fa->ord_read * fa->ord_stride : nullptr;

@@ -122,6 +122,8 @@ typedef struct rt_counters_detail {
     uint64_t primary_rays_formed; /* pixels of the tiles that are actually traced (rt_counters.primary_rays counts every pixel) */
     uint64_t cubic_points;        /* (ABI 3) degree-3 surfaces: evaluations of F, grad F and the half Hessian at a ray origin (lanes); the data
                                    * of the frame's own origin comes from the host and is not counted */
+    uint64_t cubic_refused;       /* (ABI 3) of tests_executed[3]: tests whose Taylor-form answer the guard refused (rt_math.hpp, cubic_guarded) and
+                                   * that went through the reference's dense expansion and solver instead */
 } rt_counters_detail;
 
 typedef struct rt_ctx rt_ctx;

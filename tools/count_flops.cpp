@@ -43,6 +43,9 @@ struct Counted {
 static_assert(sizeof(Counted) == 8, "layout of the scene records must not change");
 inline Counted sqrt(const Counted &a) { g_ops++; g_sqrt++; return Counted(std::sqrt(a.v)); }
 inline Counted fabs(const Counted &a) { return Counted(std::fabs(a.v)); }
+inline Counted fmax(const Counted &a, const Counted &b) { return Counted(std::fmax(a.v, b.v)); }
+inline Counted copysign(const Counted &a, const Counted &b) { return Counted(std::copysign(a.v, b.v)); }
+inline Counted fma(const Counted &a, const Counted &b, const Counted &c) { g_ops += 2; return Counted(std::fma(a.v, b.v, c.v)); } // a multiplication and an addition
 inline Counted cbrt(const Counted &a) { g_special++; return Counted(std::cbrt(a.v)); }
 inline Counted acos(const Counted &a) { g_special++; return Counted(std::acos(a.v)); }
 inline Counted cos(const Counted &a) { g_special++; return Counted(std::cos(a.v)); }
@@ -106,8 +109,22 @@ int main()
     // degree-3 surfaces: t3 .. t0 from the surface's Taylor data at the ray origin and the direction (rt_math.hpp, cubic_coefs), and
     // forming that data at a point (cubic_at) -- which happens once per (hit, wave that takes lights of its chunk), not per test
     CubicAt cat;
-    const long cubic_point = ops([&] { cat = cubic_at(cub, o); });
-    const long test_cubic_expand = ops([&] { cubic_coefs(cub, cat, d, t3, t2, t1, t0); });
+    // (with the error bounds cubic_guarded works with: cubic_mag_origin per point, cubic_mag_dir per test)
+    const CubicAbs cab = cubic_abs(cub);
+    CubicMag cmo, cmg;
+    const long cubic_point = ops([&] { cat = cubic_at(cub, o); cmo = cubic_mag_origin(cab, o); });
+    const long test_cubic_expand = ops([&] { cubic_coefs(cub, cat, d, t3, t2, t1, t0); cmg = cubic_mag_dir(cmo, fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z))); });
+    // the guarded solver on those coefficients, by the branch it takes (rt_math.hpp, cubic_guarded; a reciprocal or reciprocal square root
+    // estimate counts as one operation, cbrt as a special function); "decide": the shadow-ray form that stops at the largest root
+    const CubicMag tiny{1e-15, 1e-15, 1e-15, 1e-15};
+    Counted tg;
+    const long spg0 = g_special;
+    const long guarded_cardano = ops([&] { g_sink = cubic_guarded(1.0, 0.0, 1.0, 1.0, tiny, 1e6, false, tg); });
+    const long special_guarded_cardano = g_special - spg0;
+    const long guarded_trig = ops([&] { g_sink = cubic_guarded(1.0, 0.0, -3.0, 1.0, tiny, 1e6, false, tg); });
+    const long guarded_trig_decide = ops([&] { g_sink = cubic_guarded(1.0, 0.0, -3.0, 1.0, tiny, 1e6, true, tg); });
+    const long guarded_quad = ops([&] { g_sink = cubic_guarded(0.0, 1.0, -10.0, 9.0, tiny, 1e6, false, tg); });
+    const long guarded_linear = ops([&] { g_sink = cubic_guarded(0.0, 0.0, 2.0, -1.0, tiny, 1e6, false, tg); });
     const long test_cubic_dense = ops([&] { Mono mm; make_mono(mm, o, d); cubic_poly(cub, mm, t3, t2, t1, t0); }); // (the reference's expansion, term by term: the strict build)
     // --- root solves.  The deferred solve re-forms the coefficients from the table entry (second pass over the few candidates).
     auto quad_first = [&] { return ops([&] { g_sink = solve_quadlin(1.0, -10.0, 9.0) > 0.0; }); };   // first root accepted
@@ -171,6 +188,9 @@ int main()
                 test_cubic_expand, cubic_point, test_cubic_dense);
     std::printf("  \"solve_unitsq\": %.1f,\n  \"solve_quadric\": %.1f,\n  \"solve_linear\": %ld,\n", recompute_us + solve_quadlin_mean, recompute_gq + solve_quadlin_mean, solve_linear);
     std::printf("  \"cubic_cardano\": %ld,\n  \"cubic_trig\": %ld,\n  \"cubic_quadratic\": %.1f,\n  \"cubic_linear\": %ld,\n", solve_cardano, solve_trig, solve_quadlin_mean, solve_linear);
+    std::printf("  \"cubic_guarded_cardano\": %ld,\n  \"cubic_guarded_trig\": %ld,\n  \"cubic_guarded_trig_decide\": %ld,\n  \"cubic_guarded_quadratic\": %ld,\n  \"cubic_guarded_linear\": %ld,\n", guarded_cardano,
+                guarded_trig, guarded_trig_decide, guarded_quad, guarded_linear);
+    (void) special_guarded_cardano;
     std::printf("  \"tile_planes\": %ld,\n", tile_planes_ops);
     std::printf("  \"cull_tile\": %ld,\n  \"cull_primary\": %ld,\n  \"cull_shadow_directional\": %ld,\n  \"cull_shadow_point\": %ld,\n  \"cull_record\": %ld,\n  \"cull_shadow_box\": %ld,\n", cull_tile, cull_primary,
                 cull_shadow_directional, cull_shadow_point, cull_record_ops, cull_shadow_box);

@@ -653,9 +653,8 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
 
     for (size_t j = 0; j * RT_NCOEF < ctx->cub_coefs.size(); j++) { // degree-3 objects: F, grad F, half Hessian at the frame's ray origin (rt_math.hpp, cubic_at)
         const rtm::CubicAt a = rtm::cubic_at(ctx->cub_coefs.data() + j * RT_NCOEF, rtm::D3{fa.origin[0], fa.origin[1], fa.origin[2]});
-        const rtm::CubicAbs ab = rtm::cubic_abs(ctx->cub_coefs.data() + j * RT_NCOEF); // the bounds cubic_guarded works with (same functions as on the device)
-        const rtm::CubicMag mg = rtm::cubic_mag_origin(ab, rtm::D3{fa.origin[0], fa.origin[1], fa.origin[2]});
-        const double v[RT_CUB_REC] = {a.f, a.gx, a.gy, a.gz, a.hxx, a.hyy, a.hzz, a.hxy, a.hxz, a.hyz, mg.m3, mg.m2, mg.m1, mg.m0};
+        const rtm::CubicAbs ab = rtm::cubic_abs(ctx->cub_coefs.data() + j * RT_NCOEF); // what cubic_guarded's error bounds follow from (same function as on the device)
+        const double v[RT_CUB_REC] = {a.f, a.gx, a.gy, a.gz, a.hxx, a.hyy, a.hzz, a.hxy, a.hxz, a.hyz};
         const double va[4] = {ab.a3, ab.a2, ab.a1, ab.a0};
         std::memcpy(fa.cub_rec[j], v, sizeof(v));
         std::memcpy(fa.cub_abs[j], va, sizeof(va));

@@ -162,17 +162,17 @@ struct FrameArgs {
     uint32_t frame_tag;   // unique per frame of this context, never 0, < 2^29
     uint32_t n_scan;      // classifying workgroups in this launch
     uint32_t lean;        // 1: all-sphere scene without mirrors, dense output: the wave-per-block instantiation renders it (rt_wavefront.hip, "the lean path")
-    // Degree-3 surfaces: the record (rtm::CubicAt -- F, grad F, half Hessian: ten doubles -- and rtm::CubicMag, the error bounds that go with it:
-    // four) of the first RT_CUB_AT_MAX of them at the ray origin of the frame -- constants of all primary rays, set per frame by rt_render
+    // Degree-3 surfaces: the record (rtm::CubicAt -- F, grad F, half Hessian: ten doubles) of the first RT_CUB_AT_MAX of them at the ray origin of the frame -- constants of all primary rays, set per frame by rt_render
     // (further objects and other origins are evaluated by the kernel) -- and their rtm::CubicAbs (per object)
-    double cub_rec[4][14];
-    double cub_abs[4][4];
+    double cub_rec[4][10];
+    double cub_abs[4][4];   // (directly behind cub_rec: the kernel copies both to LDS in one sweep)
     uint32_t lights_plain; // lean path: every directional light has flags 2 and 4 of LightK (finite colours, |sdir|^2 > EPS): the specialised light loop applies
     uint32_t pt_mask[2];  // lean path: bit l = light l is a point light (at most 64 lights there; scenes with more take the general instantiation)
 };
 
 #define RT_CUB_AT_MAX 4    // FrameArgs::cub_rec
-#define RT_CUB_REC 14      // doubles per record
+#define RT_CUB_REC 10      // doubles per record (rtm::CubicAt)
+static_assert(offsetof(FrameArgs, cub_abs) == offsetof(FrameArgs, cub_rec) + sizeof(double) * 4 * RT_CUB_REC, "cub_abs directly behind cub_rec");
 #define RT_TILE 16        // a workgroup renders a 16 x 16 pixel tile
 #define RT_SCAN_TILES 64  // tiles classified by one classifying workgroup: sixteen per wave
 #define RT_PAINT_TILES 16 // tiles one paint workgroup is responsible for: four per wave

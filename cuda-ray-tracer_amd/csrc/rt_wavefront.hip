@@ -137,7 +137,7 @@ template <bool COUNT, bool HAS_GQ, bool HAS_CUBIC, bool HAS_MIRROR, bool LEAN = 
 constexpr int wf_occupancy()
 {
     if (LEAN) return COUNT ? 3 : (RT_FAST ? RT_WF_LEAN_OCC - 1 : RT_WF_LEAN_OCC); // (the FMA build's schedule needs two registers more) // the wave-per-block path (see "the lean path" in the kernel): no hit queue, few live values
-    int occ = HAS_CUBIC ? 2 : (HAS_MIRROR ? (HAS_GQ ? 3 : 4) : (HAS_GQ ? 3 : 6)); // 80 / 128 / 168 / ~200 VGPRs (strict, no counters); the
+    int occ = HAS_CUBIC ? ((!HAS_MIRROR && !HAS_GQ) ? 4 : 2) : (HAS_MIRROR ? (HAS_GQ ? 3 : 4) : (HAS_GQ ? 3 : 6)); // 80 / 128 / 168 / ~200 VGPRs (strict, no counters); the
                                                                                   // mirror-free general-quadric one needs 129-130 at 4.
     // Spheres and planes without mirrors run at SIX workgroups per CU (80 VGPRs, and an LDS carve-up that fits six times into 160 KB:
     // LdsLayout): same-box A/B against five -- 1080p 46.2 -> 44.3 us, 4K 127.6 -> 119.2, 8K 474 -> 428, orbit pose 19 59.2 -> 54.8.
@@ -234,32 +234,35 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // ---- degree-3 objects: one test, out of line ----
-// The surface's Taylor data at the ray origin and the error bounds that go with it (rt_math.hpp: CubicAt, CubicMag) wait in LDS as a
-// record of RT_CUB_REC doubles: rec + i * stride (bytes) is double i -- stride 8 for the packed records of the frame's origin, 8 * WG for
-// the per-hit / per-lane ones.  Out of line (one copy per kernel, like the dense path it falls back to) and with few arguments: inlined
-// at both call sites the guarded solver costs the instantiation a wave per SIMD.
+// The surface's Taylor data at the ray origin (rt_math.hpp: CubicAt) waits in LDS as a record of RT_CUB_REC doubles: rec + i * stride (bytes)
+// is double i -- stride 8 for the packed records of the frame's origin, 8 * WG for the per-hit / per-lane ones; the object's CubicAbs (four
+// doubles, from which the error bounds at this origin follow) likewise at abs + i * abs_stride.  Out of line (one copy per kernel, like the
+// dense path it falls back to) and with few arguments: inlined at both call sites the guarded solver costs the instantiation a wave per SIMD.
 typedef const __attribute__((address_space(3))) double *LdsD;
 __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t) (uintptr_t) (const __attribute__((address_space(3))) void *) p; }
-__device__ __forceinline__ void cubic_rec_store(double *rec, uint32_t stride_d, const CubicAt &a, const CubicMag &m)
+__device__ __forceinline__ void cubic_rec_store(double *rec, uint32_t stride_d, const CubicAt &a)
 {
     rec[0] = a.f; rec[stride_d] = a.gx; rec[2 * stride_d] = a.gy; rec[3 * stride_d] = a.gz;
     rec[4 * stride_d] = a.hxx; rec[5 * stride_d] = a.hyy; rec[6 * stride_d] = a.hzz; rec[7 * stride_d] = a.hxy; rec[8 * stride_d] = a.hxz; rec[9 * stride_d] = a.hyz;
-    rec[10 * stride_d] = m.m3; rec[11 * stride_d] = m.m2; rec[12 * stride_d] = m.m1; rec[13 * stride_d] = m.m0;
 }
 template <bool DENSE_INLINE>
-__device__ __forceinline__ double cubic_test_body(const double *c, uint32_t rec, uint32_t stride, double ox, double oy, double oz, double dx, double dy, double dz, double max_t, bool decide,
+__device__ __forceinline__ double cubic_test_body(const double *c, uint32_t rec_, uint32_t abs_, double ox, double oy, double oz, double dx, double dy, double dz, double max_t, bool decide,
                                                   bool &refused)
 {
+    // (bit 0 of either address: per-lane data, stride 8 * WG -- else packed, stride 8; LDS addresses of doubles are multiples of 8)
+    const uint32_t rec = rec_ & ~1u, stride = (rec_ & 1u) ? WG * 8u : 8u, abs = abs_ & ~1u, abs_stride = (abs_ & 1u) ? WG * 8u : 8u;
 #define RT_REC(i) (*(LdsD) (uintptr_t) (rec + (i) * stride))
+#define RT_ABS(i) (*(LdsD) (uintptr_t) (abs + (i) * abs_stride))
     const CubicAt ca{RT_REC(0), RT_REC(1), RT_REC(2), RT_REC(3), RT_REC(4), RT_REC(5), RT_REC(6), RT_REC(7), RT_REC(8), RT_REC(9)};
-    const CubicMag mo{RT_REC(10), RT_REC(11), RT_REC(12), RT_REC(13)};
+    const CubicMag mo = cubic_mag_origin(CubicAbs{RT_ABS(0), RT_ABS(1), RT_ABS(2), RT_ABS(3)}, D3{ox, oy, oz});
 #undef RT_REC
+#undef RT_ABS
     return intersect_cubic_taylor<DENSE_INLINE>(c, ca, mo, D3{ox, oy, oz}, D3{dx, dy, dz}, max_t, decide, refused);
 }
-__device__ __noinline__ double cubic_test(const double *c, uint32_t rec, uint32_t stride, double ox, double oy, double oz, double dx, double dy, double dz, double max_t, bool decide)
+__device__ __noinline__ double cubic_test(const double *c, uint32_t rec, uint32_t abs, double ox, double oy, double oz, double dx, double dy, double dz, double max_t, bool decide)
 {
     bool refused;
-    return cubic_test_body<true>(c, rec, stride, ox, oy, oz, dx, dy, dz, max_t, decide, refused);
+    return cubic_test_body<true>(c, rec, abs, ox, oy, oz, dx, dy, dz, max_t, decide, refused);
 }
 
 // Cross-lane helpers.  Reductions run on DPP row operations (VALU latency) instead of ds_bpermute round trips
@@ -649,27 +652,30 @@ __device__ __forceinline__ void nearest(const FrameArgs &fa, const SceneLds &S, 
                 // primary rays the origin is the frame's, and rt_render has evaluated the data of the first RT_CUB_AT_MAX degree-3 objects
                 // there (S.cubprim, copied at staging); other rays form it in their lane's working record.  Where the guard refuses, the
                 // reference's dense expansion and solver.
-                uint32_t rec, stride;
+                uint32_t rec, abs = S.cubprim + RT_CUB_AT_MAX * (RT_CUB_REC * 8u) + j * 32u; // (bit 0 of an address: per-lane data, see cubic_test_body)
                 if (PRIMARY && j < RT_CUB_AT_MAX) {
                     rec = S.cubprim + j * (RT_CUB_REC * 8u);
-                    stride = 8u;
                 } else {
-                    rec = S.cubtmp + (threadIdx.x << 3);
-                    stride = WG * 8u;
-                    cubic_rec_store(S.cubtmp_p + threadIdx.x, WG, cubic_at(gobj[k].c, m.o),
-                                    cubic_mag_origin(j < RT_CUB_AT_MAX ? CubicAbs{fa.cub_abs[j][0], fa.cub_abs[j][1], fa.cub_abs[j][2], fa.cub_abs[j][3]} : cubic_abs(gobj[k].c), m.o));
+                    rec = (S.cubtmp + (threadIdx.x << 3)) | 1u;
+                    cubic_rec_store(S.cubtmp_p + threadIdx.x, WG, cubic_at(gobj[k].c, m.o));
+                    if (j >= RT_CUB_AT_MAX) { // (beyond the objects whose CubicAbs the frame arguments carry: formed here, behind the lane's working record)
+                        const CubicAbs ab = cubic_abs(gobj[k].c);
+                        double *q = S.cubtmp_p + RT_CUB_REC * WG + threadIdx.x;
+                        q[0] = ab.a3; q[WG] = ab.a2; q[2 * WG] = ab.a1; q[3 * WG] = ab.a0;
+                        abs = (S.cubtmp + (threadIdx.x << 3) + RT_CUB_REC * WG * 8u) | 1u;
+                    }
                     cnt.cubic_point();
                 }
                 double t;
                 if (COUNT) { // counting builds also report which solver branch ran (flop accounting of bench.py): the guard answers only where the
                     int br;  // branch is beyond doubt, so the dense classification names it either way
                     bool refused;
-                    t = cubic_test_body<false>(gobj[k].c, rec, stride, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, MAX_T, false, refused);
+                    t = cubic_test_body<false>(gobj[k].c, rec, abs, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, MAX_T, false, refused);
                     (void) intersect_cubic_branch(gobj[k].c, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, br);
                     cnt.cubic(br);
                     cnt.cubic_refused(refused);
                 } else {
-                    t = cubic_test(gobj[k].c, rec, stride, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, MAX_T, false);
+                    t = cubic_test(gobj[k].c, rec, abs, m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, MAX_T, false);
                 }
                 accept(t, (int) k, best_t, best);
             }
@@ -724,12 +730,13 @@ struct LdsLayout {
         box = off; off = align16(off + 4 * (uint32_t) sizeof(BoxH));
         crec = off; off = align16(off + 4 * n_crec * (uint32_t) sizeof(CullRec));
         misc = off; off = align16(off + 64);
-        // degree-3 scenes: RT_CUB_REC doubles per record (rt_math.hpp: CubicAt + the origin's error bounds) -- one per hit, at its shadow-ray origin
-        // (first degree-3 object; SoA, stride WG), one per lane as working space (rays that do not start at the frame's origin, further
-        // degree-3 objects: only scenes with mirrors or several such objects), and RT_CUB_AT_MAX packed ones at the frame's origin
+        // degree-3 scenes: RT_CUB_REC doubles per record (rt_math.hpp: CubicAt) -- one per hit, at its shadow-ray origin (first degree-3 object;
+        // SoA, stride WG), one per lane as working space (+ 4 for a CubicAbs: rays that do not start at the frame's origin, further degree-3
+        // objects -- only scenes with mirrors or several such objects), and RT_CUB_AT_MAX packed ones at the frame's origin, followed by
+        // the CubicAbs of those objects.  (The per-hit records are what decides how many workgroups a CU holds: 20 KB.)
         cubrec = off; off = align16(off + (n_cub ? RT_CUB_REC * WG * 8u : 0u));
-        cubtmp = off; off = align16(off + ((n_cub > 1u || (n_cub && has_mirror)) ? RT_CUB_REC * WG * 8u : 0u));
-        cubprim = off; off = align16(off + (n_cub ? RT_CUB_REC * RT_CUB_AT_MAX * 8u : 0u));
+        cubtmp = off; off = align16(off + ((n_cub > 1u || (n_cub && has_mirror)) ? (RT_CUB_REC + 4u) * WG * 8u : 0u));
+        cubprim = off; off = align16(off + (n_cub ? (RT_CUB_REC + 4u) * RT_CUB_AT_MAX * 8u : 0u));
         total = off;
     }
 };
@@ -849,23 +856,28 @@ __device__ __forceinline__ int shadow_blocker(const FrameArgs &fa, const SceneLd
             if (valid && (int) k < blocker && (COUNT || blocker == NO_BLOCKER)) {
                 // the surface's Taylor data at the shadow-ray origin is the same for every light: phase A' has put the first degree-3 object's
                 // into the hit's record (cub_rec0: its LDS address); further objects form theirs in the lane's working record
-                uint32_t rec = cub_rec0;
+                uint32_t rec = cub_rec0 | 1u, abs = S.cubprim + RT_CUB_AT_MAX * (RT_CUB_REC * 8u) + j * 32u;
                 if (j != 0) {
-                    rec = S.cubtmp + (threadIdx.x << 3);
-                    cubic_rec_store(S.cubtmp_p + threadIdx.x, WG, cubic_at(gobj[k].c, sm.o),
-                                    cubic_mag_origin(j < RT_CUB_AT_MAX ? CubicAbs{fa.cub_abs[j][0], fa.cub_abs[j][1], fa.cub_abs[j][2], fa.cub_abs[j][3]} : cubic_abs(gobj[k].c), sm.o));
+                    rec = (S.cubtmp + (threadIdx.x << 3)) | 1u;
+                    cubic_rec_store(S.cubtmp_p + threadIdx.x, WG, cubic_at(gobj[k].c, sm.o));
+                    if (j >= RT_CUB_AT_MAX) {
+                        const CubicAbs ab = cubic_abs(gobj[k].c);
+                        double *q = S.cubtmp_p + RT_CUB_REC * WG + threadIdx.x;
+                        q[0] = ab.a3; q[WG] = ab.a2; q[2 * WG] = ab.a1; q[3 * WG] = ab.a0;
+                        abs = (S.cubtmp + (threadIdx.x << 3) + RT_CUB_REC * WG * 8u) | 1u;
+                    }
                     if (prod) cnt.cubic_point();
                 }
                 double t;
                 if (COUNT) {
                     int br;
                     bool refused;
-                    t = cubic_test_body<false>(gobj[k].c, rec, WG * 8u, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z, max_t, true, refused);
+                    t = cubic_test_body<false>(gobj[k].c, rec, abs, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z, max_t, true, refused);
                     (void) intersect_cubic_branch(gobj[k].c, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z, br);
                     cnt.cubic(br, prod);
                     if (prod) cnt.cubic_refused(refused);
                 } else {
-                    t = cubic_test(gobj[k].c, rec, WG * 8u, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z, max_t, true);
+                    t = cubic_test(gobj[k].c, rec, abs, sm.o.x, sm.o.y, sm.o.z, sm.d.x, sm.d.y, sm.d.z, max_t, true);
                 }
                 if (t > EPS && t < max_t) blocker = (int) k;
             }
@@ -1576,7 +1588,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
             // writes all of them -- the same values to the same words -- and reads them back only after its own stores (LDS operations of a
             // wave complete in order): no workgroup barrier in front of round 0.
             double *prim = reinterpret_cast<double *>(smem + L.cubprim);
-            if (lane < RT_CUB_REC * RT_CUB_AT_MAX) prim[lane] = (&fa.cub_rec[0][0])[lane];
+            if (lane < (RT_CUB_REC + 4) * RT_CUB_AT_MAX) prim[lane] = (&fa.cub_rec[0][0])[lane]; // (cub_rec[4][10], then cub_abs[4][4]: contiguous in FrameArgs)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         }
@@ -1711,8 +1723,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     const D3 so{px + SHADOW_BIAS * hn[hs], py + SHADOW_BIAS * hn[WG + hs], pz + SHADOW_BIAS * hn[2 * WG + hs]};
                     const double *c0 = gobj[__builtin_amdgcn_readfirstlane(S.cub[0])].c;
                     if (v) {
-                        cubic_rec_store(reinterpret_cast<double *>(smem + L.cubrec) + tid, WG, cubic_at(c0, so),
-                                        cubic_mag_origin(CubicAbs{fa.cub_abs[0][0], fa.cub_abs[0][1], fa.cub_abs[0][2], fa.cub_abs[0][3]}, so));
+                        cubic_rec_store(reinterpret_cast<double *>(smem + L.cubrec) + tid, WG, cubic_at(c0, so));
                         cnt.cubic_point();
                     }
                 }
@@ -1917,7 +1928,7 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
         // ... and so are the frame's sizes: read through a fresh pointer to the arguments, they are short-lived scalar loads here instead of
         // SGPRs (or, as it happened, a spill slot that was rematerialised away but still cost the kernel a private segment) across all phases
         // (Only where registers are the limit -- spheres and planes without mirrors, six workgroups per CU; the other instantiations lose a per cent with it.)
-        constexpr bool LEAN_REGS = !HAS_GQ && !HAS_CUBIC && !HAS_MIRROR;
+        constexpr bool LEAN_REGS = !HAS_GQ && !HAS_MIRROR; // (and the degree-3 one without general quadrics: 128 VGPRs, four workgroups per CU)
         const FrameArgs &fe = LEAN_REGS ? cold_args().fa : fa;
         const uint32_t tid_ = LEAN_REGS ? tid ^ s_zero[0] : tid; // (an LDS word that is always 0: the compiler cannot know, so it cannot keep x / y of round 0 alive instead)
         const uint32_t sx_ = (tile % fe.tiles_x) * RT_TILE + tile_px(tid_), sy_ = (tile / fe.tiles_x) * RT_TILE + tile_py(tid_);

@@ -9,6 +9,7 @@
 #ifndef RT_SCENE_DEV_H
 #define RT_SCENE_DEV_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 // coefficient indices, order of SurfaceCoefs (include/surface.h:10-15)

@@ -432,34 +432,34 @@ static int g_cub_why = 0;
 #endif
 
 // Reciprocals.  cub_rcpa: a few good digits are enough (error bounds, Newton corrections) -- on the device the bare v_rcp_f64, one
-// instruction where a division is a dozen; taken to be good to 2^-12 and never trusted beyond that (the host stand-in is made that bad
-// on purpose when RT_CUB_LAB is set, so the CPU experiment covers it).  cub_rcp: full precision, two Newton steps on top.
+// instruction where a division is a dozen.  Measured on gfx950 (scratch probe, 2^24 arguments over 16 binades): v_rcp_f64 and v_rsq_f64 are
+// good to 2^-24.4 / 2^-24.2; the code trusts them to 2^-20 (the host stand-in is made 2^-21 wrong on purpose when RT_CUB_LAB is set, so
+// the CPU experiment covers it).  cub_rcp: one Newton step on top -- 2^-40 at worst by that assumption, 2^-48 as measured; what is left
+// is part of the relative uncertainty the callers book for it (r3 below).
 __host__ __device__ __forceinline__ double cub_rcpa(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_rcp(x);
 #elif defined(RT_CUB_LAB)
-    return (1.0 / x) * (1.0 + 0x1p-13);
+    return (1.0 / x) * (1.0 + 0x1p-21);
 #else
     return 1.0 / x;
 #endif
 }
 __host__ __device__ __forceinline__ double cub_rcp(double x)
 {
-    double y = cub_rcpa(x);
-    y = fma(y, fma(-x, y, 1.0), y);
-    y = fma(y, fma(-x, y, 1.0), y);
-    return y;
+    const double y = cub_rcpa(x);
+    return fma(y, fma(-x, y, 1.0), y);
 }
 
-// Square roots of this function's own intermediate values: v_rsq_f64 and two coupled Newton steps (no scaling for denormal or huge
+// Square roots of this function's own intermediate values: v_rsq_f64, a coupled Newton step and a correction (no scaling for denormal or huge
 // arguments -- an argument out there ends in inf / NaN, which every check below refuses).  cub_rsqa: a few good digits (error bounds).
 __host__ __device__ __forceinline__ double cub_rsqa(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_rsq(x);
 #elif defined(RT_CUB_LAB)
-    return (1.0 / sqrt(x)) * (1.0 + 0x1p-13);
+    return (1.0 / sqrt(x)) * (1.0 + 0x1p-21);
 #else
     return 1.0 / sqrt(x);
 #endif
@@ -468,13 +468,10 @@ __host__ __device__ __forceinline__ double cub_sqrt(double x)
 {
     const double y = cub_rsqa(x);
     double g = x * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
+    const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    return fma(fma(-g, g, x), h, g); // (one more correction of g alone: the result is within an ulp or two)
+    return fma(fma(-g, g, x), h, g); // (one coupled step, one more correction of g alone: 2^-20 -> 2^-39 -> below 2^-50)
 }
 
 // false: no verdict (take the reference's path).  true: `t` is what the reference's solver returns for this ray up to CUB_TOL, and
@@ -491,7 +488,7 @@ __host__ __device__ __forceinline__ bool cubic_guarded(double t3, double t2, dou
     if (at3 > EPS + (EPS + CUB_K * e3)) { // ---- solve_cubic, include/surface_impl.h:106-136 ----
         const double inv = cub_rcp(t3), ainv = fabs(inv);
         const double a2 = t2 * inv, a1 = t1 * inv, a0 = t0 * inv;
-        const double r3 = e3 * ainv + 4.0 * CUB_U; // relative uncertainty of 1 / t3
+        const double r3 = e3 * ainv + 0x1p-39;      // relative uncertainty of 1 / t3 (its own rounding: cub_rcp)
         const double ea2 = fma(mg.m2, ainv, fabs(a2) * r3);
         const double ea1 = fma(mg.m1, ainv, fabs(a1) * r3);
         const double ea0 = fma(mg.m0, ainv, fabs(a0) * r3);
@@ -516,22 +513,23 @@ __host__ __device__ __forceinline__ bool cubic_guarded(double t3, double t2, dou
             const double cb = -q * ra;
             const double rb = cub_rcpa(cb); // (cb = 0: infinite -- refused below)
             root = (ca + cb) - third_a2;
-            eroot = fma(eab * (1.0 / 3.0), fma(ra, ra, rb * rb), fma(eq, fabs(ra), ea2 * (1.0 / 3.0)));
+            eroot = fma(eab * (1.0 / 3.0), fma(ra, ra, rb * rb), fma(eq, fabs(ra), ea2 * (1.0 / 3.0))) + 0x1p-39 * fabs(cb); // (the last term: ra's own rounding)
         } else {
             // three real roots 2 m cos(theta + 2 k pi / 3) - a2 / 3, cos(3 theta) = r / m^3.  No acos / cos: c = cos(theta) is the root of
-            // 4 c^3 - 3 c = arg in [1/2, 1], four Newton steps from 1/2 + sqrt((1 + arg) / 8) (good to 0.016: 8e-4, 2e-6, 3e-10, 3e-14 with a
-            // reciprocal that is only good to 2^-13); the size of the last correction -- the error before it -- is taken as the error after it.  sin(theta) >= 0 from c.
+            // 4 c^3 - 3 c = arg in [1/2, 1], four Newton steps from 1/2 + sqrt((1 + arg) / 8) (good to 0.016: then 8e-4, 2e-6, 2e-11, 1e-16);
+            // the size of the last correction -- the error before it -- is taken as the error after it.  sin(theta) >= 0 from c.
             const double m2 = -q; // > 0: delta < 0 means q^3 < -r^2 <= 0
             const double m = cub_sqrt(m2);
             const double rm = cub_rcp(m), rm3 = rm * rm * rm;
             const double em = 0.5 * eq * rm;
             const double arg = r * rm3;
-            const double earg = fma(3.0 * fabs(arg) * m2, em, er) * rm3;
+            const double earg = fma(fma(3.0 * fabs(arg) * m2, em, er), rm3, 0x1p-38 * fabs(arg)); // (the last term: rm's own rounding, three times)
             const double w2 = -delta * (rm3 * rm3); // 1 - arg^2, without the cancellation
             double c = 0.5 + (double) sqrtf((float) fma(0.125, arg, 0.125));
             double dc = 0.0;
 #pragma unroll
             for (int it = 0; it < 4; it++) {
+                if (it == 3 && decide) break; // (a decision does with three steps: the bands below just get wider)
                 const double c2 = c * c;
                 dc = fma(fma(4.0, c2, -3.0), c, -arg) * cub_rcpa(fma(12.0, c2, -3.0));
                 c -= dc;
@@ -579,7 +577,7 @@ __host__ __device__ __forceinline__ bool cubic_guarded(double t3, double t2, dou
             }
             const double s = cub_sqrt(delta), es = ed * cub_rcpa(s);
             const double h = 0.5 * cub_rcp(t2), ah = fabs(h);
-            const double rel2 = 2.0 * e2 * ah + 4.0 * CUB_U;
+            const double rel2 = 2.0 * e2 * ah + 0x1p-39;
             const double en = e1 + es; // of the numerators -t1 -+ s
             const double xa = (-t1 - s) * h;
             const double exa = fma(en, ah, fabs(xa) * rel2);
@@ -595,7 +593,7 @@ __host__ __device__ __forceinline__ bool cubic_guarded(double t3, double t2, dou
             if (at1 > EPS + (EPS + CUB_K * e1)) {
                 const double r1 = cub_rcp(t1);
                 root = -t0 * r1;
-                eroot = fma(fabs(root), e1, e0) * fabs(r1) + (4.0 * CUB_U) * fabs(root);
+                eroot = fma(fabs(root), e1, e0) * fabs(r1) + 0x1p-39 * fabs(root);
             } else if (at1 + CUB_K * e1 < EPS) {
                 t = -1.0;
                 return true;

@@ -9,6 +9,7 @@
 //
 // bench.py multiplies these costs with the device's work counters (rt_get_counters_detail).
 #include <cmath>
+#include <cstddef> // (before `double` is redefined below: rt_scene_dev.h includes it too)
 #include <cstdint>
 #include <cstdio>
 #include <cstring>

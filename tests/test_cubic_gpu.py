@@ -61,3 +61,31 @@ def test_fast_build_uses_the_same_guard(pkg, oracle):
     want = oracle.load_scene(scene_path("clebsch")).with_size(w, h).render(nthreads=8)
     c = compare(got[..., :3], want)
     assert c["n_bad_pixels"] <= max(2, int(0.0004 * w * h)), c
+
+
+def test_many_cubic_objects_and_mirrors(pkg, oracle):
+    """More degree-3 objects than the frame arguments carry data for (RT_CUB_AT_MAX = 4: objects 5 and 6 form their CubicAbs in the lane's
+    working record), next to spheres and a mirror plane -- bounce rays form their Taylor records per lane.  Wavefront == simple kernel bit for
+    bit (they share the guarded path), both within 1e-5 of the oracle."""
+    from test_gpu_parity import oracle_from, render_desc
+    rng = np.random.default_rng(4242)
+    w, h = 200, 150
+    s = pkg.Scene.new(w, h, 50.0, 3, (0.1, 0.2, 0.3))
+    for k in range(6):
+        q = np.zeros(20)
+        q[:10] = rng.uniform(-0.3, 0.3, 10) * (rng.random(10) < 0.6)
+        q[10:13] = rng.uniform(0.5, 1.5, 3)           # mostly an ellipsoid, bent by the cubic terms
+        c = np.array([-5.0 + 2.0 * k, float(rng.uniform(-1, 1)), 6.0 + 0.8 * k])
+        # shift the surface to c:  F(x - c)  expanded only approximately is fine for a test -- use the linear and constant terms
+        q[16:19] = -2.0 * q[10:13] * c
+        q[19] = float(np.sum(q[10:13] * c * c) - 1.0)
+        s.add_object(q, rng.uniform(0.2, 1, 3), 0.4 if k % 2 else 0.0)
+    s.add_object(pkg.surface_make("sphere", [0.0, 1.5, 9.0], [1.0]), (0.9, 0.2, 0.2), 0.5)
+    s.add_object(pkg.surface_make("plane", [0, -2.5, 0], [0.0, 1.0, 0.0]), (0.5, 0.5, 0.5), 0.3)
+    s.add_light("directional", [0.3, -1.0, 0.4], (1, 1, 1), 1.0)
+    s.add_light("spherical", [0.0, 8.0, 2.0], (1, 0.9, 0.8), 200.0)
+    got = render_desc(pkg, s)
+    assert np.array_equal(got, render_desc(pkg, s, flags=pkg.RT_FLAG_SIMPLE))
+    want = oracle_from(pkg, oracle, s).render(nthreads=8)
+    c = compare(got[..., :3], want)
+    assert c["n_bad_pixels"] <= max(3, int(0.002 * w * h)), c

@@ -639,10 +639,11 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
     // frame and wins wherever the GPU is full (4K 120 -> 91 us, 8K 425 -> 306, the 1080p start pose 44 -> 38).  The general one splits
     // costly tiles over two workgroups and every tile's lights over its four waves, which is what counts while few tiles have hits and
     // the frame ends with its slowest wave (orbit poses 5 / 6 at 1080p: 40 us against 54).  The previous frames' count of tiles with
-    // hits decides, with a hysteresis: lean from 0.65 of the workgroup slots up, back below 0.55.
+    // hits decides, with a hysteresis: lean from 0.66 of the workgroup slots up, back below 0.62 (the orbit of tools/flythrough_bench.py: the
+    // general one wins every pose below 950 tiles for 1536 slots and loses every pose above 975; a wider band kept poses 3 and 4 on the wrong side).
     if (ctx->lean_ok && ctx->h_listed && ctx->lean_force == 0) {
         const uint32_t tiles = ((volatile uint32_t *) ctx->h_listed)[2]; // tiles with hits a few frames ago (listed, or the census' estimate while the lists are off)
-        if (ctx->lean_now ? (uint64_t) tiles * 100u < (uint64_t) ctx->wg_slots * 55u : (uint64_t) tiles * 100u >= (uint64_t) ctx->wg_slots * 65u) ctx->lean_now = !ctx->lean_now;
+        if (ctx->lean_now ? (uint64_t) tiles * 100u < (uint64_t) ctx->wg_slots * 62u : (uint64_t) tiles * 100u >= (uint64_t) ctx->wg_slots * 66u) ctx->lean_now = !ctx->lean_now;
     } else {
         ctx->lean_now = ctx->lean_force >= 0;
     }

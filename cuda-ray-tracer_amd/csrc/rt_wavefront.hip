@@ -1569,7 +1569,8 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 if (hm != 0ull) __hip_atomic_fetch_add(&s_cost[0], (uint32_t) (b_ticks >> 6) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t before = __hip_atomic_fetch_add(&s_done[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (before == 3u) {
-                    const uint32_t cost = __hip_atomic_load(&s_cost[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t cost4 = __hip_atomic_load(&s_cost[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t cost = (cost4 + 3u) >> 2; // per wave: the scale the other schedule reports on (its slowest wave's time), so that a switch does not leave the scale a factor of four off
                     if (cost != 0u) { // the tile has hits
                         if (((tile * 0x9E3779B1u) >> 28) == 0u) atomicAdd(&ord_wr[16], 1u); // census, also while the ordering is off
                         if (listing) {

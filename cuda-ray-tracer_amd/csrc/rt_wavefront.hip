@@ -357,10 +357,14 @@ __device__ __forceinline__ OrdHeader ord_header(Words rd, uint32_t split_arg = 0
     // of the `split` costliest classes gets TWO consecutive positions in the launch order: rows 0-7 of the tile and rows 8-15, each by
     // a workgroup of its own whose other two waves have no pixels but take their share of the shadow items.  Positions, not entries,
     // are what the list slots index:  position p < 2 * n_heavy -> entry p / 2, half 1 + (p & 1);  otherwise entry p - n_heavy, whole tile.
+    // While the GPU holds two workgroups for EVERY listed tile, every tile is split (orbit poses 5 / 6: 712 - 746 tiles for 1536 slots); above
+    // that only the costliest classes are: splitting most but not all tiles, or the cheap ones, costs more than it brings (pose 7, 839 tiles:
+    // 36 us with the heavy ones split, 42 with everything the spare slots allow).
     const uint32_t spare = slots > h.n_listed ? slots - h.n_listed : 0u;
     h.n_heavy = 0;
 #pragma unroll
     for (uint32_t k = 0; k < ORD_CLASSES; k++) h.n_heavy += k < split ? h.cnt[k] : 0u;
+    if (split != 0u && h.n_listed * 2u <= slots) h.n_heavy = h.n_listed;
     if (h.n_listed * 4u > slots * 3u) h.n_heavy = 0;
     h.n_candidates = h.n_heavy; // (none while the GPU is full: list slots that only leave again are not free there)
     h.n_heavy = h.n_heavy < spare ? h.n_heavy : spare;
@@ -1574,10 +1578,10 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                     if (cost != 0u) { // the tile has hits
                         if (((tile * 0x9E3779B1u) >> 28) == 0u) atomicAdd(&ord_wr[16], 1u); // census, also while the ordering is off
                         if (listing) {
-                            const uint32_t q = cost_scale ? (uint32_t) (((unsigned long long) cost * ORD_CLASSES) / ((unsigned long long) cost_scale + 1ull)) : ORD_CLASSES - 1u;
+                            const uint32_t q = cost_scale ? (uint32_t) (((unsigned long long) cost * ORD_CLASSES) / ((unsigned long long) cost_scale + 1ull)) : 0u; // (no scale yet: the cheapest class -- nothing is split on a guess)
                             ord_cls = ORD_CLASSES - (q < ORD_CLASSES - 1u ? q : ORD_CLASSES - 1u); // class + 1
                             ord_pos = atomicAdd(&ord_wr[ord_cls - 1u], 1u);
-                            if (cost > cost_scale - cost_scale / 4u) atomicMax(&ord_wr[17], cost);
+                            if (cost > cost_scale - cost_scale / 4u || ((tile * 0x9E3779B1u) >> 28) == 0u) atomicMax(&ord_wr[17], cost); // (see the other schedule's report)
                         }
                     }
                 }
@@ -1827,11 +1831,14 @@ __global__ __launch_bounds__(256, (wf_occupancy<COUNT, HAS_GQ, HAS_CUBIC, HAS_MI
                 // (plus one for the scale), their results only needed at the very end of the workgroup.  A half tile reports twice its own
                 // cost -- what the whole tile would have cost, or a little more: once split, a tile stays split.
                 const uint32_t cost = s_half[0] ? 2u * s_cost[0] : s_cost[0];
-                const uint32_t q = cost_scale ? (uint32_t) (((unsigned long long) cost * ORD_CLASSES) / ((unsigned long long) cost_scale + 1ull)) : ORD_CLASSES - 1u;
+                const uint32_t q = cost_scale ? (uint32_t) (((unsigned long long) cost * ORD_CLASSES) / ((unsigned long long) cost_scale + 1ull)) : 0u; // (no scale yet: the cheapest class -- nothing is split on a guess)
                 ord_cls = ORD_CLASSES - (q < ORD_CLASSES - 1u ? q : ORD_CLASSES - 1u); // class + 1
                 ord_pos = atomicAdd(&ord_wr[ord_cls - 1u], 1u);
-                if (cost > cost_scale - cost_scale / 4u) atomicMax(&ord_wr[17], cost); // (only candidates for the maximum bother the counter; if the
-                                                                                         // scene got so much lighter that nobody qualifies, the scale restarts from 0)
+                // (only candidates for the maximum bother the counter -- and one tile in sixteen whatever its cost, the census' sample: when every
+                // cost has dropped below the old scale, e.g. after a frame whose tiles were all split and reported twice a half's cost, the next
+                // scale is the sample's maximum instead of nothing.  A scale that restarted from 0 put every tile into the costliest class: all
+                // split, in arrival order, inflated costs, no candidate again -- a three-frame cycle of 43 / 50 / 72 us at orbit pose 6.)
+                if (cost > cost_scale - cost_scale / 4u || ((tile * 0x9E3779B1u) >> 28) == 0u) atomicMax(&ord_wr[17], cost);
             }
 
             // ---------------- phase C: shade each hit, lights in order ----------------

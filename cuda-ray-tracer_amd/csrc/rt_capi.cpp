@@ -647,6 +647,10 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
     } else {
         ctx->lean_now = ctx->lean_force >= 0;
     }
+    static const bool debug_order = std::getenv("MI355RT_DEBUG_ORDER") != nullptr; // (diagnostics: what the previous frames' kernels reported back)
+    if (debug_order && ctx->h_listed)
+        std::fprintf(stderr, "mi355rt: frame %llu: tiles with hits %u, list slots wanted %u, census %u, schedule %s\n", (unsigned long long) ctx->frame, ((volatile uint32_t *) ctx->h_listed)[2],
+                     ((volatile uint32_t *) ctx->h_listed)[0], ((volatile uint32_t *) ctx->h_listed)[1], ctx->lean_now ? "lean" : "general");
     fa.lean = (ctx->lean_ok && ctx->lean_now && !sparse) ? 1u : 0u;
     std::memcpy(fa.cam, cam, sizeof(double) * 16);
     // g_ray_origin = camera_matrix * (0,0,0,1), src/update-cpu.cpp:123 -- glm order (m0*x + m1*y) + (m2*z + m3*w)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # The evidence of a round, on the GPU box: tests, bench, rocprofv3 kernel stats + PMC passes (config 2 and config 4), timeline / phase
 # shares of the stamped diagnostic build, orbit, all configs, A/B of the two sphere instantiations, fuzz.  Everything lands under
-# gpurun_out/$1 (default r3/final3); the summaries worth judging are copied into profiles/ by hand afterwards.
+# gpurun_out/$1 (default r3/final6); the summaries worth judging are copied into profiles/ by hand afterwards.
 # A step that is killed at its time limit stops the pass (nothing further touches the GPU after a hang).
 # PART=1 tests / bench / A-B / timelines, PART=2 rocprofv3 kernel stats + PMC passes, PART=3 fuzz: one gpurun call each.
-O=gpurun_out/${1:-r3/final3}
+O=gpurun_out/${1:-r3/final6}
 mkdir -p $O
 step() { t=$1; out=$2; shift 2; echo "== [$t s] $*"; timeout -k 10 $t bash -c "$*" > $out 2>&1; rc=$?; echo "rc=$rc"; tail -n 2 $out | cut -c1-300; if [ $rc -ge 124 ]; then echo "step killed: stopping"; exit $rc; fi; }
 if [ "${PART:-1}" = 1 ]; then

@@ -735,9 +735,13 @@ static int render_impl(rt_ctx *ctx, const double cam[16], void *dev_fb, void *st
             const uint64_t want = (uint64_t) seen + seen / 4u + 64u;
             if (want < cap) cap = (uint32_t) want;
             const uint64_t with_hits = (uint64_t) census * 16u;
-            // ... and while so many tiles have hits that the launch is more than a dozen rounds of workgroups deep anyway (8K: 20 000 tiles, 16
-            // rounds): there the order buys nothing any more (measured: 477 us either way) and the lists only cost their upkeep
-            const bool too_many = ctx->ord_on ? with_hits >= 16384u : with_hits >= 12288u;
+            // ... and while so many tiles have hits that the launch is many rounds of workgroups deep anyway: there the order buys nothing any
+            // more and the lists only cost their upkeep -- the decode in front of every list slot.  Measured with the lean schedule (index
+            // order against lists): 2 rounds (4K orbit pose 5) 81 -> 69 us with the lists, 3.7 rounds (4K pose 19) 117 -> 109, 4.3 rounds (4K pose
+            // 16) 119 / 120, 7.5 - 8 rounds (8K poses 5 / 6) 206 -> 243 and 197 -> 233, 12.7 rounds (8K start pose) 288 / 293.  Off from 16 / 3
+            // rounds, back on below 4.
+            const uint64_t slots = ctx->wg_slots ? ctx->wg_slots : 1536u;
+            const bool too_many = ctx->ord_on ? with_hits * 3u >= slots * 16u : with_hits >= slots * 4u;
             const bool too_dense = ctx->ord_on ? with_hits * 4u >= fa.n_tiles : with_hits * 5u >= fa.n_tiles;
             ctx->ord_on = !(too_many || too_dense);
         }

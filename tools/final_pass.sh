@@ -4,6 +4,9 @@
 # gpurun_out/$1 (default r3/final6); the summaries worth judging are copied into profiles/ by hand afterwards.
 # A step that is killed at its time limit stops the pass (nothing further touches the GPU after a hang).
 # PART=1 tests / bench / A-B / timelines, PART=2 rocprofv3 kernel stats + PMC passes, PART=3 fuzz: one gpurun call each.
+# PART=1 needs two libraries under tools/bin/ that are NOT kept there between rounds (tools/bin is pruned at round end so that only the product
+# ships to the GPU box): libmi355rt_stamped.so (`make -C cuda-ray-tracer_amd all STAMPS=1 SPILLS_OK=1`, copy, then `make all` again for the product)
+# and, for the A/B against an older round, libmi355rt_rN.so built from that round's tag.  Steps whose library is missing fail and are skipped over.
 O=gpurun_out/${1:-r3/final6}
 mkdir -p $O
 step() { t=$1; out=$2; shift 2; echo "== [$t s] $*"; timeout -k 10 $t bash -c "$*" > $out 2>&1; rc=$?; echo "rc=$rc"; tail -n 2 $out | cut -c1-300; if [ $rc -ge 124 ]; then echo "step killed: stopping"; exit $rc; fi; }

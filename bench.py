@@ -594,7 +594,7 @@ def measure_config(pkg, graft, name, device, flags, table, frames, check_rows):
         want = O.load_scene(path).with_size(W, H, max_refl).render(rows=rows, nthreads=min(16, os.cpu_count() or 1))
         got = img[rows][..., :3]
         diff = np.abs(got.astype(np.float64) - want)
-        rel = diff / np.maximum(np.maximum(np.abs(got), np.abs(want)), 1e-300)
+        rel = diff / np.maximum(np.maximum(np.abs(got), np.abs(want)).astype(np.float64), 1e-300)   # (float64: 1e-300 is 0 in float32, and 0 / 0 a warning)
         out["oracle_row_sample"] = {"rows": int(rows.size), "identical": bool(np.array_equal(got, want)),
                                     "pixels_over_1e-5": int(((rel > 1e-5) & (diff > 1e-7)).any(axis=-1).sum()), "pixels": int(rows.size * W)}
     r.cleanup_update()

@@ -81,6 +81,11 @@ def test_many_cubic_objects_and_mirrors(pkg, oracle):
         q[19] = float(np.sum(q[10:13] * c * c) - 1.0)
         s.add_object(q, rng.uniform(0.2, 1, 3), 0.4 if k % 2 else 0.0)
     s.add_object(pkg.surface_make("sphere", [0.0, 1.5, 9.0], [1.0]), (0.9, 0.2, 0.2), 0.5)
+    e = np.zeros(20)   # an ellipsoid (general quadric class): 2 (x + 3)^2 + 0.5 (y - 2)^2 + (z - 7)^2 = 1 -- the instantiation with every feature
+    e[10:13] = (2.0, 0.5, 1.0)
+    e[16:19] = (12.0, -2.0, -14.0)
+    e[19] = 18.0 + 2.0 + 49.0 - 1.0
+    s.add_object(e, (0.2, 0.4, 0.9), 0.3)
     s.add_object(pkg.surface_make("plane", [0, -2.5, 0], [0.0, 1.0, 0.0]), (0.5, 0.5, 0.5), 0.3)
     s.add_light("directional", [0.3, -1.0, 0.4], (1, 1, 1), 1.0)
     s.add_light("spherical", [0.0, 8.0, 2.0], (1, 0.9, 0.8), 200.0)

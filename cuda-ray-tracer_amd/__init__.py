@@ -39,6 +39,7 @@ ABI_SYMBOLS = [
 MULTI_ABI_SYMBOLS = ["rt_create_multi", "rt_render_multi", "rt_multi_wait", "rt_multi_fb", "rt_multi_stream", "rt_multi_download", "rt_multi_info",
                      "rt_multi_destroy"]
 RT_MULTI_SELF_EXCHANGE = 0x10000
+RT_MULTI_BANDWISE = 0x20000
 
 
 class RtError(RuntimeError):

@@ -68,6 +68,9 @@ struct rt_multi {
     size_t pixel_bytes = 16, slot_bytes = 0, full_bytes = 0;
     Transport transport = DIRECT;
     bool self_exchange = false;
+    bool bandwise = false;            // RT_MULTI_BANDWISE: rows travel band by band straight to their place in the full frame; no rank-major slots, no rt_assemble
+    uint32_t band_rows = 16;
+    std::vector<uint32_t> rows;       // [world] local rows of context q (bandwise)
     std::vector<int> dev;              // [n]
     std::vector<rt_ctx *> ctx;         // [world], context q = part * n + r lives on device r and is rank q of `world`
     std::vector<hipStream_t> s_render, s_comm; // [n]
@@ -124,6 +127,8 @@ static int create_impl(rt_multi *m, const rt_scene_desc *sd, const int *devices,
     m->height = sd->height;
     m->pixel_bytes = format == RT_FMT_RGBA8 ? 4 : 16;
     m->self_exchange = (flags & RT_MULTI_SELF_EXCHANGE) != 0;
+    m->bandwise = (flags & RT_MULTI_BANDWISE) != 0;
+    m->band_rows = band_rows;
     m->dev.assign(devices, devices + n);
     bool all_same = true, all_distinct = true;
     for (uint32_t a = 0; a < n; a++)
@@ -153,7 +158,7 @@ static int create_impl(rt_multi *m, const rt_scene_desc *sd, const int *devices,
         cfg.rank = q;
         cfg.world = m->world;
         cfg.band_rows = band_rows;
-        cfg.flags = flags & ~RT_MULTI_SELF_EXCHANGE;
+        cfg.flags = flags & ~(RT_MULTI_SELF_EXCHANGE | RT_MULTI_BANDWISE);
         cfg.format = format;
         int rc = rt_create(&m->ctx[q], sd, &cfg);
         if (rc != RT_OK) return rc;
@@ -162,14 +167,17 @@ static int create_impl(rt_multi *m, const rt_scene_desc *sd, const int *devices,
         M_HIP(hipEventCreateWithFlags(&m->ev_sent[q], hipEventDisableTiming));
         if (q == 0) rt_max_local_rows(m->ctx[0], &max_rows);
     }
+    m->rows.assign(m->world, 0);
+    for (uint32_t q = 0; q < m->world; q++) rt_local_rows(m->ctx[q], &m->rows[q]);
+    if (m->bandwise && m->world == 1 && m->transport == DIRECT) m->bandwise = false; // (one context renders in place: nothing travels)
     m->slot_bytes = (size_t) max_rows * sd->width * m->pixel_bytes;
     m->full_bytes = (size_t) sd->height * sd->width * m->pixel_bytes;
     M_HIP(hipSetDevice(devices[0]));
     M_HIP(hipMalloc(&m->full, m->full_bytes ? m->full_bytes : 16));
-    if (m->world > 1 || m->transport == RCCL) M_HIP(hipMalloc(&m->gathered, m->slot_bytes * m->world + 16));
+    if ((m->world > 1 || m->transport == RCCL) && !m->bandwise) M_HIP(hipMalloc(&m->gathered, m->slot_bytes * m->world + 16));
     for (uint32_t q = 0; q < m->world; q++) { // rows that have to travel get a buffer on their own device
         const uint32_t r = q % n;
-        const bool travels = m->transport == RCCL ? (r != 0 || m->self_exchange) : (m->transport == LOCAL_COPY && r != 0);
+        const bool travels = m->bandwise || (m->transport == RCCL ? (r != 0 || m->self_exchange) : (m->transport == LOCAL_COPY && r != 0)); // (bandwise: the root's own rows are strided in the frame too)
         if (!travels) continue;
         M_HIP(hipSetDevice(devices[r]));
         M_HIP(hipMalloc(&m->local[q], m->slot_bytes ? m->slot_bytes : 16));
@@ -235,6 +243,64 @@ extern "C" int rt_render_multi(rt_multi *m, const double cam[16], void *root_ful
     if (m->world == 1 && m->transport == DIRECT) { // one device, one part: the frame is this context's rows
         int rc = rt_render(m->ctx[0], cam, full, m->s_render[0], nullptr);
         if (rc != RT_OK) return rc;
+    } else if (m->bandwise) {
+        // Rows go band by band straight to where they belong in the full frame ("band-wise ncclRecv straight into final row
+        // offsets"): band j of context q is rows (j W + q) B ... of the frame.  No rank-major receive slots and no reassembly pass over the
+        // frame on the root.  Between distinct devices: one ncclSend / ncclRecv pair per band, all bands of a part in one group; rows that are
+        // already on the root device (and every row in the one-GPU rehearsal) take ONE strided device copy per context.
+        const size_t row_bytes = (size_t) m->width * m->pixel_bytes, band_bytes = row_bytes * m->band_rows;
+        const size_t dst_pitch = band_bytes * m->world;
+        for (uint32_t p = 0; p < P; p++) {
+            for (uint32_t r = 0; r < n; r++) {
+                const uint32_t q = p * n + r;
+                M_HIP(hipSetDevice(m->dev[r]));
+                M_HIP(hipStreamWaitEvent(m->s_render[r], m->ev_sent[q], 0)); // the previous frame's rows have left this buffer
+                int rc = rt_render(m->ctx[q], cam, m->local[q], m->s_render[r], nullptr);
+                if (rc != RT_OK) return rc;
+                M_HIP(hipEventRecord(m->ev_rendered[q], m->s_render[r]));
+                M_HIP(hipStreamWaitEvent(m->s_comm[r], m->ev_rendered[q], 0));
+            }
+            const bool by_rccl = m->transport == RCCL;
+            if (by_rccl) M_NCCL(ncclGroupStart());
+            ncclResult_t in_group = ncclSuccess;
+            hipError_t copy_err = hipSuccess;
+            for (uint32_t r = 0; r < n && in_group == ncclSuccess && copy_err == hipSuccess; r++) {
+                const uint32_t q = p * n + r;
+                const uint32_t full_bands = m->rows[q] / m->band_rows, tail_rows = m->rows[q] - full_bands * m->band_rows;
+                char *dst0 = (char *) full + (size_t) q * band_bytes; // context q's band j starts dst_pitch * j further on
+                if (by_rccl && (r != 0 || m->self_exchange)) {
+                    for (uint32_t j = 0; j * m->band_rows < m->rows[q] && in_group == ncclSuccess; j++) {
+                        const size_t bytes = j < full_bands ? band_bytes : (size_t) tail_rows * row_bytes;
+                        in_group = ncclSend((const char *) m->local[q] + (size_t) j * band_bytes, bytes, ncclInt8, 0, m->comm[r], m->s_comm[r]);
+                        if (in_group == ncclSuccess) in_group = ncclRecv(dst0 + (size_t) j * dst_pitch, bytes, ncclInt8, (int) r, m->comm[0], m->s_comm[0]);
+                    }
+                } else { // same device as the frame: one strided copy (and one more for a last, shorter band)
+                    (void) hipSetDevice(m->dev[r]);
+                    if (full_bands) copy_err = hipMemcpy2DAsync(dst0, dst_pitch, m->local[q], band_bytes, band_bytes, full_bands, hipMemcpyDeviceToDevice, m->s_comm[r]);
+                    if (copy_err == hipSuccess && tail_rows)
+                        copy_err = hipMemcpyAsync(dst0 + (size_t) full_bands * dst_pitch, (const char *) m->local[q] + (size_t) full_bands * band_bytes, (size_t) tail_rows * row_bytes,
+                                                  hipMemcpyDeviceToDevice, m->s_comm[r]);
+                }
+            }
+            if (by_rccl) {
+                const ncclResult_t closed = ncclGroupEnd(); // (a failure inside the group still closes it before this call returns)
+                if (in_group != ncclSuccess) return fail(RT_ERR_DEVICE, "ncclSend / ncclRecv of part %u failed: %s", p, ncclGetErrorString(in_group));
+                M_NCCL(closed);
+            }
+            if (copy_err != hipSuccess) return fail(RT_ERR_DEVICE, "band copy of part %u failed: %s", p, hipGetErrorString(copy_err));
+            for (uint32_t r = 0; r < n; r++) {
+                const uint32_t q = p * n + r;
+                M_HIP(hipSetDevice(m->dev[r]));
+                M_HIP(hipEventRecord(m->ev_sent[q], m->s_comm[r]));
+                if (r != 0 || !by_rccl) { // what ran on another comm stream than the root's: the root's comm stream waits for it
+                    M_HIP(hipSetDevice(m->dev[0]));
+                    M_HIP(hipStreamWaitEvent(m->s_comm[0], m->ev_sent[q], 0));
+                }
+            }
+        }
+        M_HIP(hipSetDevice(m->dev[0]));
+        M_HIP(hipEventRecord(m->ev_gathered, m->s_comm[0]));
+        M_HIP(hipStreamWaitEvent(m->s_render[0], m->ev_gathered, 0)); // the frame is complete for whatever follows on the root's render stream
     } else {
         // the root's receive slots are free again once the previous frame has been reassembled out of them
         if (m->have_assembled)

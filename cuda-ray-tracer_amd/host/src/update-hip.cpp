@@ -170,7 +170,8 @@ void init_update(unsigned int texture, const Scene &scene)
     const std::vector<int> devs = device_list();
     if (devs.size() > 1 || (devs.size() == 1 && std::getenv("MI355RT_MULTI_SELF"))) {
         load_multi();
-        const uint32_t flags = RT_FLAG_STRICT | (std::getenv("MI355RT_MULTI_SELF") ? RT_MULTI_SELF_EXCHANGE : 0u);
+        const uint32_t flags = RT_FLAG_STRICT | (std::getenv("MI355RT_MULTI_SELF") ? RT_MULTI_SELF_EXCHANGE : 0u) |
+                               (std::getenv("MI355RT_MULTI_BANDWISE") ? RT_MULTI_BANDWISE : 0u); // (rows band by band into their place in the frame: no reassembly pass)
         if (g_mapi.create(&g_multi, &sd, devs.data(), (uint32_t) devs.size(), env_u32("MI355RT_BAND_ROWS", 16), env_u32("MI355RT_PARTS", 2), flags, g_format) != RT_OK)
             die("init_update (MI355RT_DEVICES)");
         return;

@@ -262,6 +262,8 @@ int rt_destroy(rt_ctx *ctx);
  * ------------------------------------------------------------------------------------------------- */
 #define RT_MULTI_SELF_EXCHANGE 0x10000u /* one device: send its rows to itself through RCCL instead of rendering in place
                                            (exercises the RCCL path on a one-GPU box) */
+#define RT_MULTI_BANDWISE 0x20000u      /* rows travel band by band straight into their place in the full frame (one ncclSend / ncclRecv pair per band,
+                                         * one strided copy per context on the root device): no rank-major receive slots, no rt_assemble pass */
 typedef struct rt_multi rt_multi;
 int rt_create_multi(rt_multi **out, const rt_scene_desc *scene, const int *devices, uint32_t n_devices, uint32_t band_rows, uint32_t parts,
                     uint32_t flags, uint32_t format);

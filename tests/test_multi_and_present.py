@@ -67,6 +67,47 @@ def test_repeated_device_choreography(pkg, devices, parts, band, fmt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("devices,parts,band,fmt,size", [([0, 0, 0], 1, 8, 0, (400, 277)), ([0, 0, 0, 0], 2, 16, 0, (400, 277)), ([0, 0, 0, 0], 2, 16, 1, (333, 256)),
+                                                         ([0], 3, 16, 0, (400, 277)), ([0, 0], 4, 4, 0, (129, 31))])
+def test_bandwise_transport_matches_single_context(pkg, devices, parts, band, fmt, size):
+    """RT_MULTI_BANDWISE: every context's rows go band by band (one strided copy per context on this one-GPU box) straight to their place in
+    the full frame -- no rank-major slots, no rt_assemble.  Heights that are and are not multiples of the band (a shorter last band), more
+    contexts than bands on some ranks, both formats; three frames with a moving camera, each equal to the single-context frame, and equal
+    to what the classic transport delivers."""
+    w, h = size
+    sc = pkg.Scene.load_from_file(scene_path("20spheres")).set_size(w, h)
+    ref = pkg.Renderer(sc, device=0, fmt=fmt)
+    m = pkg.MultiRenderer(sc, devices, band_rows=band, parts=parts, fmt=fmt, flags=pkg.RT_MULTI_BANDWISE)
+    classic = pkg.MultiRenderer(sc, devices, band_rows=band, parts=parts, fmt=fmt)
+    assert m.n_contexts == len(devices) * parts
+    for k in range(3):
+        cam = pkg.camera_matrix((0.5 * k, 0.2 * k, -1.0 * k), 90.0 + 4.0 * k, 1.0 * k)
+        ref.update(cam)
+        m.update(cam, timed=(k != 1))   # the middle frame enqueue-only
+        classic.update(cam)
+        got = m.download()
+        assert np.array_equal(got, ref.download()), k
+        assert np.array_equal(got, classic.download()), k
+    m.cleanup_update()
+    classic.cleanup_update()
+
+
+@pytest.mark.gpu
+def test_bandwise_rccl_self_exchange_in_a_plain_host_process(pkg, oracle, tmp_path):
+    """The same through RCCL: one rank sends every band of its rows to itself with ncclSend / ncclRecv pairs in one group per part, the
+    receives pointing into the final frame (MI355RT_MULTI_SELF=1 MI355RT_MULTI_BANDWISE=1; a process without PyTorch)."""
+    assert os.path.exists(EXE)
+    out = str(tmp_path / "f.f32")
+    w, h = 320, 203
+    env = dict(os.environ, MI355RT_DEVICES="0", MI355RT_MULTI_SELF="1", MI355RT_MULTI_BANDWISE="1", MI355RT_PARTS="2")
+    p = subprocess.run([EXE, scene_path("20spheres"), str(w), str(h), "-1", out, "--frames", "3"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = np.fromfile(out, dtype=np.float32).reshape(h, w, 4)
+    want = oracle.load_scene(scene_path("20spheres")).with_size(w, h).render(nthreads=8)
+    assert np.array_equal(got[..., :3], want)
+
+
+@pytest.mark.gpu
 def test_rccl_self_exchange_in_a_plain_host_process(pkg, oracle, tmp_path):
     """update() over `MI355RT_DEVICES=0` + MI355RT_MULTI_SELF=1: libmi355rt_multi.so creates a one-rank RCCL communicator and the
     rows travel through ncclSend / ncclRecv before rt_assemble (a process without PyTorch: the system's librccl)."""

@@ -127,3 +127,17 @@ extern "C" void lab_run(const orc_scene *scene, const double cam[16], LabStats *
         }
     free(blk);
 }
+
+// cubic_guarded itself, for unit tests: returns 1 (answered; *t = the root the callers compare) or 0 (refused).  m[4] = the uncertainties m3 .. m0.
+extern "C" int lab_guard(double t3, double t2, double t1, double t0, const double m[4], double max_t, int decide, double *t)
+{
+    double r = 0.0;
+    const bool ok = cubic_guarded(t3, t2, t1, t0, CubicMag{m[0], m[1], m[2], m[3]}, max_t, decide != 0, r);
+    *t = r;
+    return ok ? 1 : 0;
+}
+// the reference's solver on the same coefficients (rt_math.hpp: solve_cubic / solve_quadlin, as intersect_cubic chains them)
+extern "C" double lab_reference(double t3, double t2, double t1, double t0)
+{
+    return fabs(t3) > EPS ? solve_cubic(t3, t2, t1, t0) : solve_quadlin(t2, t1, t0);
+}
